@@ -1,0 +1,198 @@
+/*
+ * fdtd_engine.h -- C ABI of the MI355X (gfx950) FDTD time-stepping engine.
+ *
+ * The engine replaces the per-step hot path of the two reference solvers:
+ *   3-D: FDTD3D::updateE(int) + FDTD3D::updateH()      (fdtd3d/include/FDTD3D.h:190-195,
+ *        bodies fdtd3d/src/FDTD3D.cpp:480-1021; called from FDTD3D::run(), :1085-1086)
+ *   2-D: FDTD2D::stepOnce(int)                          (fdtd2d/include/FDTD2D.h:88-89,
+ *        body fdtd2d/src/FDTD2D.cpp:275-482; called from FDTD2D::run(), :512)
+ *
+ * In the reference these are private void member functions acting on private
+ * std::vector<double> members; there is no error path.  Here the state lives in
+ * device memory behind an opaque handle, the caller hands over the setup results
+ * (material arrays, CPML tables, source) once, and every call returns an int
+ * status (0 = ok) with a thread-local message behind fdtd_last_error().
+ *
+ * Host arrays crossing this boundary are always double, in the reference's own
+ * flat order ("canonical order"): 3-D [i][j][k] with k unit-stride
+ * (FDTD3D.h:115-125), 2-D [i][k] with k unit-stride (FDTD2D.h:70-76).  The engine
+ * converts to its own device layout (x unit-stride, z slowest, rows padded to
+ * 256 elements) and to the compute precision (fp32 or fp64) internally.
+ */
+#ifndef FDTD_ENGINE_H
+#define FDTD_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDTD_OK 0
+#define FDTD_ERR_ARG 1      /* bad descriptor / id / size                      */
+#define FDTD_ERR_HIP 2      /* a HIP runtime call failed (message has details) */
+#define FDTD_ERR_STATE 3    /* call not valid for this handle                  */
+
+/* Message for the last failing call on this thread ("" if none). */
+const char* fdtd_last_error(void);
+/* Library build identification ("fdtd_engine gfx950 ..."). */
+const char* fdtd_engine_version(void);
+
+/* ------------------------------------------------------------------ 3-D -- */
+
+/* Array ids, 3-D.  Shapes (canonical order, k fastest), from FDTD3D.h:31-51:
+ *   Dx,Ex,eps_x [Nx][Ny+1][Nz+1]   Dy,Ey,eps_y [Nx+1][Ny][Nz+1]   Dz,Ez,eps_z [Nx+1][Ny+1][Nz]
+ *   Bx,Hx,mu_x  [Nx+1][Ny][Nz]     By,Hy,mu_y  [Nx][Ny+1][Nz]     Bz,Hz,mu_z  [Nx][Ny][Nz+1] */
+enum {
+    FDTD3D_DX = 0, FDTD3D_DY = 1, FDTD3D_DZ = 2,
+    FDTD3D_EX = 3, FDTD3D_EY = 4, FDTD3D_EZ = 5,
+    FDTD3D_BX = 6, FDTD3D_BY = 7, FDTD3D_BZ = 8,
+    FDTD3D_HX = 9, FDTD3D_HY = 10, FDTD3D_HZ = 11,
+    FDTD3D_EPS_X = 12, FDTD3D_EPS_Y = 13, FDTD3D_EPS_Z = 14,
+    FDTD3D_MU_X = 15, FDTD3D_MU_Y = 16, FDTD3D_MU_Z = 17,   /* extension: reference has mu0 only */
+    /* CPML auxiliary fields (FDTD3D.h:80-103).  id = base + (comp*3 + axis)*2 + side,
+     * comp = component of D (resp. B) the term updates (0=x,1=y,2=z), axis = derivative
+     * axis (!= comp), side 0 = low face, 1 = high face.  Canonical shape = the shape of
+     * that D (resp. B) component with the extent along `axis` replaced by the layer
+     * count of that face; the entry for cell (i,j,k) in layer l sits at the cell's own
+     * transverse indices (the reference's per-array index shifts, FDTD3D.h:136-182, are
+     * undone).  Entries no sweep touches are zero. */
+    FDTD3D_PHI_E = 100,
+    FDTD3D_PHI_M = 200,
+    /* CPML 1-D tables (FDTD3D.h:58-78).  id = base + (axis*2 + side)*6 + kind,
+     * kind: 0 b_e, 1 a_e, 2 C_e (=dt/d/kappa_e), 3 b_m, 4 a_m, 5 C_m; length = layers. */
+    FDTD3D_TAB = 300,
+    FDTD3D_JX_MAG = 400,      /* [Nx][Ny+1], FDTD3D.h:107 */
+    FDTD3D_JX_WF = 401        /* [n_wf],     FDTD3D.h:108 */
+};
+
+/* Storage modes. */
+#define FDTD3D_MODE_FULL 0   /* D,E,B,H all resident (the reference's formulation)            */
+#define FDTD3D_MODE_LEAN 1   /* only D,B resident; E=D/eps, H=B/mu recomputed where consumed */
+
+typedef struct fdtd3d_desc {
+    int32_t struct_size;      /* sizeof(fdtd3d_desc), for forward compatibility             */
+    int32_t Nx, Ny, Nz;       /* global cell counts (FDTD3D.h:25)                            */
+    int32_t n_pml[6];         /* xn, xp, yn, yp, zn, zp (FDTD3D.h:54-56)                    */
+    int32_t k_Jx;             /* source plane (FDTD3D.h:106)                                 */
+    int32_t n_wf;             /* waveform length (m_steps)                                   */
+    int32_t precision;        /* 32 or 64                                                    */
+    int32_t has_mu;           /* 0: H = B/mu0 (reference), 1: H = B/mu_{x,y,z}               */
+    int32_t mode;             /* FDTD3D_MODE_*                                               */
+    int32_t z_lo, z_hi;       /* owned cell layers [z_lo, z_hi); 0,Nz = whole grid           */
+    int32_t device;           /* HIP device ordinal, -1 = current                            */
+    double dx, dy, dz, dt;    /* FDTD3D.h:26-28                                              */
+    double mu0;               /* FDTD3D.h:20                                                 */
+} fdtd3d_desc;
+
+typedef struct fdtd3d_engine* fdtd3d_handle;
+
+/* Allocate device state for one z-slab (fields and CPML auxiliaries zero, eps/mu = 1,
+ * tables/source empty).  Replaces the allocations of FDTD3D::setupGrid()/setupPML()
+ * (FDTD3D.cpp:41-63, :419-462). */
+int fdtd3d_create(const fdtd3d_desc* desc, fdtd3d_handle* out);
+int fdtd3d_destroy(fdtd3d_handle h);
+
+/* Number of doubles of the GLOBAL canonical array `id` (0 for an unknown id). */
+size_t fdtd3d_array_size(fdtd3d_handle h, int id);
+/* Upload from / download into a GLOBAL canonical array.  A slab engine takes the part
+ * it stores (owned layers plus its ghost planes) and, on download, writes only the
+ * layers it owns, leaving the rest of `host` untouched.  In LEAN mode E and H are
+ * computed on the fly for download and cannot be uploaded. */
+int fdtd3d_set_array(fdtd3d_handle h, int id, const double* host, size_t n);
+int fdtd3d_get_array(fdtd3d_handle h, int id, double* host, size_t n);
+
+/* Device-side synthetic materials for grids too large for host arrays:
+ * eps_c(cell) = eps_lo + (eps_hi-eps_lo)*u, u = fdtd_hash_unit(seed, c, canonical index)
+ * and likewise mu (only if has_mu).  Same function as oracle twin3d_fill_materials. */
+int fdtd3d_fill_materials(fdtd3d_handle h, uint64_t seed, double eps_lo, double eps_hi,
+                          double mu_lo, double mu_hi);
+
+/* Advance `count` whole steps n0, n0+1, ...: per step E-half (curl+CPML, source, E=D/eps;
+ * FDTD3D::updateE) then H-half (FDTD3D::updateH).  Asynchronous on `stream`
+ * (a hipStream_t, NULL = default stream).  Only valid when the slab is the whole grid. */
+int fdtd3d_step(fdtd3d_handle h, int n0, int count, void* stream);
+
+/* Half steps over a sub-range of the owned layers, for slab drivers that overlap the
+ * ghost exchange with the interior update.  part: */
+#define FDTD3D_PART_ALL 0
+#define FDTD3D_PART_EDGE 1       /* E-half: lowest owned layer; H-half: highest owned layer */
+#define FDTD3D_PART_INTERIOR 2   /* the rest                                                 */
+int fdtd3d_half_e(fdtd3d_handle h, int n, int part, void* stream);
+int fdtd3d_half_h(fdtd3d_handle h, int part, void* stream);
+
+/* Ghost-plane exchange buffers (device pointers into the engine's own arrays; each is
+ * one contiguous x-y plane of `bytes` bytes).  which: */
+#define FDTD3D_HALO_SEND_UP 0    /* tangential H (FULL) / B (LEAN), top owned layer -> rank+1 */
+#define FDTD3D_HALO_RECV_LO 1    /* ghost layer z_lo-1                             <- rank-1 */
+#define FDTD3D_HALO_SEND_DOWN 2  /* tangential E (FULL) / D (LEAN), layer z_lo     -> rank-1 */
+#define FDTD3D_HALO_RECV_HI 3    /* ghost layer z_hi                               <- rank+1 */
+/* comp 0 = x component, 1 = y component. */
+int fdtd3d_halo(fdtd3d_handle h, int which, int comp, void** dev_ptr, size_t* bytes);
+
+/* Sum over owned cells of the squares of array `id`, accumulated in double on device
+ * (diagnostic / checksum). */
+int fdtd3d_sumsq(fdtd3d_handle h, int id, double* out, void* stream);
+
+/* Bytes of device memory held by the handle. */
+size_t fdtd3d_device_bytes(fdtd3d_handle h);
+
+/* Timing hook for the dominant kernels: if enabled, every E-half / H-half launch is
+ * bracketed by HIP events on its stream; fdtd3d_kernel_time() synchronises and returns
+ * the launch count and the summed device time (ms) per kernel kind (0 = E, 1 = H). */
+int fdtd3d_kernel_timing(fdtd3d_handle h, int enable);
+int fdtd3d_kernel_time(fdtd3d_handle h, int kind, int* launches, double* total_ms);
+
+/* ------------------------------------------------------------------ 2-D -- */
+
+/* Array ids, 2-D.  Shapes (canonical order, k fastest), FDTD2D.h:33-38:
+ *   Dy,Ey,SEy (+ _n1,_n2) [Nx+1][Nz+1];  Bx,Hx,SHx (+..) [Nx+1][Nz];
+ *   Bz,Hz,SHz (+..) [Nx][Nz+1];  C1,C2,C3 [Nx][Nz]. */
+enum {
+    FDTD2D_DY = 0, FDTD2D_EY = 1, FDTD2D_EY_N1 = 2, FDTD2D_EY_N2 = 3,
+    FDTD2D_SEY = 4, FDTD2D_SEY_N1 = 5, FDTD2D_SEY_N2 = 6,
+    FDTD2D_BX = 7, FDTD2D_HX = 8, FDTD2D_HX_N1 = 9, FDTD2D_HX_N2 = 10,
+    FDTD2D_SHX = 11, FDTD2D_SHX_N1 = 12, FDTD2D_SHX_N2 = 13,
+    FDTD2D_BZ = 14, FDTD2D_HZ = 15, FDTD2D_HZ_N1 = 16, FDTD2D_HZ_N2 = 17,
+    FDTD2D_SHZ = 18, FDTD2D_SHZ_N1 = 19, FDTD2D_SHZ_N2 = 20,
+    FDTD2D_C1 = 21, FDTD2D_C2 = 22, FDTD2D_C3 = 23,
+    /* CPML auxiliaries (FDTD2D.h:53-59), canonical shape = shape of the updated field
+     * with the derivative axis replaced by the layer count (index shifts undone):
+     * 100 ey_zn 101 ey_zp 102 ey_xn 103 ey_xp 104 mx_zn 105 mx_zp 106 mz_xn 107 mz_xp */
+    FDTD2D_PHI = 100,
+    /* tables: id = base + (axis*2+side)*6 + kind, axis 0 = x, 1 = z; kinds as 3-D */
+    FDTD2D_TAB = 300,
+    FDTD2D_JY = 400           /* [n_wf], FDTD2D.h:63 */
+};
+
+typedef struct fdtd2d_desc {
+    int32_t struct_size;
+    int32_t Nx, Nz;           /* FDTD2D.h:23 */
+    int32_t n_pml[4];         /* xn, xp, zn, zp (FDTD2D.h:41) */
+    int32_t i_Jy, k_Jy;       /* source cell (FDTD2D.h:62) */
+    int32_t n_wf;
+    int32_t precision;        /* 32 or 64 */
+    int32_t device;
+    double dx, dz, dt;
+    double mu0, eps0;         /* FDTD2D.h:19-20 */
+} fdtd2d_desc;
+
+typedef struct fdtd2d_engine* fdtd2d_handle;
+
+int fdtd2d_create(const fdtd2d_desc* desc, fdtd2d_handle* out);
+int fdtd2d_destroy(fdtd2d_handle h);
+size_t fdtd2d_array_size(fdtd2d_handle h, int id);
+int fdtd2d_set_array(fdtd2d_handle h, int id, const double* host, size_t n);
+int fdtd2d_get_array(fdtd2d_handle h, int id, double* host, size_t n);
+/* Advance `count` steps n0.. (FDTD2D::stepOnce).  Asynchronous on `stream`. */
+int fdtd2d_step(fdtd2d_handle h, int n0, int count, void* stream);
+int fdtd2d_sumsq(fdtd2d_handle h, int id, double* out, void* stream);
+size_t fdtd2d_device_bytes(fdtd2d_handle h);
+int fdtd2d_kernel_timing(fdtd2d_handle h, int enable);
+int fdtd2d_kernel_time(fdtd2d_handle h, int kind, int* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDTD_ENGINE_H */
