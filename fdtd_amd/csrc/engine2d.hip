@@ -1,0 +1,285 @@
+// engine2d.hip -- host side of the 2-D engine: device state, array exchange, launches, C ABI.
+#include "kernels2d.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+using namespace fdtd;
+
+namespace fdtd {
+template <typename T>
+__global__ void k2_sumsq(const T* arr, int Nx, int px, int rows, double* partial) {
+    const size_t total = (size_t)rows * px;
+    double s = 0;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        if ((int)(t % px) >= Nx) continue;
+        const T v = arr[t];
+        s += (double)v * (double)v;
+    }
+    __shared__ double sh[256];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+}  // namespace fdtd
+
+struct fdtd2d_engine {
+    virtual ~fdtd2d_engine() {}
+    virtual size_t array_size(int id) = 0;
+    virtual int set_array(int id, const double* host, size_t n) = 0;
+    virtual int get_array(int id, double* host, size_t n) = 0;
+    virtual int step(int n0, int count, hipStream_t s) = 0;
+    virtual int sumsq(int id, double* out, hipStream_t s) = 0;
+    virtual size_t device_bytes() = 0;
+    fdtd2d_desc d;
+    KernelTimer timer;
+};
+
+namespace {
+
+template <typename T>
+struct Engine2 : fdtd2d_engine {
+    static constexpr int V = VecWidth<T>::V;
+    int px = 0, nz1 = 0, np[2][2], xwn = 0, xwp = 0, xp0 = 0;
+    size_t fsize = 0, bytes = 0;
+    T* Dy = nullptr; T* Bx = nullptr; T* Bz = nullptr;
+    T* Fa[3]; T* Fb[3]; T* Sa[3]; T* Sb[3];     // a = holds sample n-1 ("current"), b = sample n-2
+    T* C[3];
+    T* ph_z[2][2];      // [0 = ey, 1 = mx][side]   layout [l][px]
+    T* ph_x[2][2];      // [0 = ey, 1 = mz][side]   layout [k][strip]
+    T* tab_d = nullptr; T* xrow_d = nullptr; double* red_d = nullptr;
+    std::vector<double> tab_h;
+    std::vector<T> Jy;
+    int chunk = 32;
+    std::vector<void*> allocs;
+
+    ~Engine2() override { for (void* p : allocs) (void)hipFree(p); timer.release(); }
+
+    int dalloc(void** p, size_t nbytes) {
+        if (nbytes == 0) { *p = nullptr; return FDTD_OK; }
+        FDTD_HIP(hipMalloc(p, nbytes));
+        allocs.push_back(*p);
+        bytes += nbytes;
+        FDTD_HIP(hipMemset(*p, 0, nbytes));
+        return FDTD_OK;
+    }
+    int init(const fdtd2d_desc& dd) {
+        d = dd;
+        for (int a = 0; a < 2; ++a) for (int s = 0; s < 2; ++s) np[a][s] = d.n_pml[a * 2 + s];
+        px = round_up(d.Nx, kRowAlign);
+        nz1 = d.Nz + 1;
+        fsize = (size_t)nz1 * px;
+        xwn = np[0][0] > 0 ? round_up(np[0][0] + 1, 4) : 0;
+        xp0 = (d.Nx - np[0][1]) / 4 * 4;
+        xwp = np[0][1] > 0 ? round_up(d.Nx - xp0, 4) : 0;
+        if (const char* e = getenv("FDTD_Z_CHUNK2D")) { int c = atoi(e); if (c >= 1 && c <= 65536) chunk = c; }
+        int rc;
+        const size_t fb = (fsize + px) * sizeof(T);
+        if ((rc = dalloc((void**)&Dy, fb)) || (rc = dalloc((void**)&Bx, fb)) || (rc = dalloc((void**)&Bz, fb))) return rc;
+        for (int f = 0; f < 3; ++f) {
+            if ((rc = dalloc((void**)&Fa[f], fb)) || (rc = dalloc((void**)&Fb[f], fb)) || (rc = dalloc((void**)&Sa[f], fb)) ||
+                (rc = dalloc((void**)&Sb[f], fb)) || (rc = dalloc((void**)&C[f], fb))) return rc;
+        }
+        for (int w = 0; w < 2; ++w) for (int s = 0; s < 2; ++s) {
+            ph_z[w][s] = ph_x[w][s] = nullptr;
+            if (np[1][s] && (rc = dalloc((void**)&ph_z[w][s], ((size_t)np[1][s] * px + px) * sizeof(T)))) return rc;
+            if (np[0][s] && (rc = dalloc((void**)&ph_x[w][s], ((size_t)nz1 * (s ? xwp : xwn) + px) * sizeof(T)))) return rc;
+        }
+        tab_h.assign((size_t)2 * 2 * 6 * kMaxLayers, 0.0);
+        if ((rc = dalloc((void**)&tab_d, tab_h.size() * sizeof(T)))) return rc;
+        if ((rc = dalloc((void**)&xrow_d, (size_t)6 * px * sizeof(T)))) return rc;
+        if ((rc = dalloc((void**)&red_d, 1024 * sizeof(double)))) return rc;
+        Jy.assign(d.n_wf > 0 ? d.n_wf : 0, (T)0);
+        return FDTD_OK;
+    }
+    size_t device_bytes() override { return bytes; }
+
+    struct Map { int n0 = 0, n1 = 0; T* dev = nullptr; size_t dev_elems = 0; int kind = -1, s = 0; bool mag = false; };
+    bool make_map(int id, Map& m) {
+        if (id >= 0 && id <= 20) {
+            const int f = id / 7, r = id % 7;
+            m.n0 = d.Nx + (f != 2); m.n1 = d.Nz + (f != 1);
+            m.kind = 0; m.dev_elems = fsize;
+            if (r == 0) m.dev = f == 0 ? Dy : (f == 1 ? Bx : Bz);
+            else if (r == 1 || r == 2) m.dev = Fa[f];
+            else if (r == 3) m.dev = Fb[f];
+            else if (r == 4 || r == 5) m.dev = Sa[f];
+            else m.dev = Sb[f];
+            return true;
+        }
+        if (id >= FDTD2D_C1 && id <= FDTD2D_C3) { m.n0 = d.Nx; m.n1 = d.Nz; m.kind = 0; m.dev = C[id - FDTD2D_C1]; m.dev_elems = fsize; return true; }
+        if (id >= FDTD2D_PHI && id < FDTD2D_PHI + 8) {
+            const int w = (id - FDTD2D_PHI) / 2; m.s = (id - FDTD2D_PHI) % 2;
+            m.mag = w >= 2;
+            if (w == 0 || w == 2) { m.kind = 1; m.n0 = d.Nx + 1; m.n1 = np[1][m.s]; m.dev = ph_z[w / 2][m.s]; m.dev_elems = (size_t)np[1][m.s] * px; }
+            else { m.kind = 2; m.n0 = np[0][m.s]; m.n1 = d.Nz + 1; m.dev = ph_x[w / 2][m.s]; m.dev_elems = (size_t)nz1 * (m.s ? xwp : xwn); }
+            return true;
+        }
+        return false;
+    }
+    long long dev_off(const Map& m, int p0, int p1) const {
+        switch (m.kind) {
+            case 0: return p0 >= d.Nx ? -1 : (long long)p1 * px + p0;       // canonical (i,k) -> [k][i]
+            case 1: return p0 >= d.Nx ? -1 : (long long)p1 * px + p0;       // canonical (i,l) -> [l][i]
+            case 2: {                                                        // canonical (l,k) -> [k][column - origin]
+                const int col = m.s ? d.Nx - np[0][1] + p0 : (m.mag ? p0 : 1 + p0);
+                if (col < 0 || col >= d.Nx) return -1;
+                return m.s ? (long long)p1 * xwp + (col - xp0) : (long long)p1 * xwn + col;
+            }
+        }
+        return -1;
+    }
+    size_t array_size(int id) override {
+        Map m;
+        if (make_map(id, m)) return (size_t)m.n0 * m.n1;
+        if (id >= FDTD2D_TAB && id < FDTD2D_TAB + 24) return np[(id - FDTD2D_TAB) / 12][((id - FDTD2D_TAB) / 6) % 2];
+        if (id == FDTD2D_JY) return Jy.size();
+        return 0;
+    }
+    int upload_tables() {
+        std::vector<T> t(tab_h.size());
+        for (size_t q = 0; q < t.size(); ++q) t[q] = (T)tab_h[q];
+        FDTD_HIP(hipMemcpy(tab_d, t.data(), t.size() * sizeof(T), hipMemcpyHostToDevice));
+        std::vector<T> xr((size_t)6 * px, (T)0);
+        auto tb = [&](int s, int kind, int l) { return (T)tab_h[((size_t)s * 6 + kind) * kMaxLayers + l]; };
+        for (int i = 0; i < d.Nx; ++i) {
+            int l;
+            int z = zone_e(i, d.Nx, np[0][0], np[0][1], l);
+            if (z == Z_NEG || z == Z_POS) for (int q = 0; q < 3; ++q) xr[(size_t)q * px + i] = tb(z == Z_POS, q, l);
+            z = zone_h(i, d.Nx, np[0][0], np[0][1], false, l);
+            if (z == Z_NEG || z == Z_POS) for (int q = 3; q < 6; ++q) xr[(size_t)q * px + i] = tb(z == Z_POS, q, l);
+        }
+        FDTD_HIP(hipMemcpy(xrow_d, xr.data(), xr.size() * sizeof(T), hipMemcpyHostToDevice));
+        return FDTD_OK;
+    }
+    int set_array(int id, const double* host, size_t n) override {
+        if (n != array_size(id) || (n && !host)) return fail(FDTD_ERR_ARG, "set_array(%d): expected %zu values, got %zu", id, array_size(id), n);
+        if (id >= FDTD2D_TAB && id < FDTD2D_TAB + 24) {
+            for (size_t q = 0; q < n; ++q) tab_h[(size_t)(id - FDTD2D_TAB) * kMaxLayers + q] = host[q];
+            return upload_tables();
+        }
+        if (id == FDTD2D_JY) { for (size_t q = 0; q < n; ++q) Jy[q] = (T)host[q]; return FDTD_OK; }
+        Map m;
+        if (!make_map(id, m)) return fail(FDTD_ERR_ARG, "set_array: unknown array id %d", id);
+        if (n == 0) return FDTD_OK;
+        std::vector<T> st(m.dev_elems);
+        FDTD_HIP(hipMemcpy(st.data(), m.dev, st.size() * sizeof(T), hipMemcpyDeviceToHost));
+        size_t o = 0;
+        for (int p0 = 0; p0 < m.n0; ++p0) for (int p1 = 0; p1 < m.n1; ++p1, ++o) {
+            const long long off = dev_off(m, p0, p1);
+            if (off >= 0) st[(size_t)off] = (T)host[o];
+        }
+        FDTD_HIP(hipMemcpy(m.dev, st.data(), st.size() * sizeof(T), hipMemcpyHostToDevice));
+        return FDTD_OK;
+    }
+    int get_array(int id, double* host, size_t n) override {
+        if (n != array_size(id) || (n && !host)) return fail(FDTD_ERR_ARG, "get_array(%d): expected %zu values, got %zu", id, array_size(id), n);
+        if (id >= FDTD2D_TAB && id < FDTD2D_TAB + 24) { for (size_t q = 0; q < n; ++q) host[q] = tab_h[(size_t)(id - FDTD2D_TAB) * kMaxLayers + q]; return FDTD_OK; }
+        if (id == FDTD2D_JY) { for (size_t q = 0; q < n; ++q) host[q] = (double)Jy[q]; return FDTD_OK; }
+        Map m;
+        if (!make_map(id, m)) return fail(FDTD_ERR_ARG, "get_array: unknown array id %d", id);
+        if (n == 0) return FDTD_OK;
+        FDTD_HIP(hipDeviceSynchronize());
+        std::vector<T> st(m.dev_elems);
+        FDTD_HIP(hipMemcpy(st.data(), m.dev, st.size() * sizeof(T), hipMemcpyDeviceToHost));
+        size_t o = 0;
+        for (int p0 = 0; p0 < m.n0; ++p0) for (int p1 = 0; p1 < m.n1; ++p1, ++o) {
+            const long long off = dev_off(m, p0, p1);
+            host[o] = off >= 0 ? (double)st[(size_t)off] : 0.0;
+        }
+        return FDTD_OK;
+    }
+    int sumsq(int id, double* out, hipStream_t s) override {
+        Map m;
+        if (!make_map(id, m) || m.kind != 0) return fail(FDTD_ERR_ARG, "sumsq: array %d is not a field", id);
+        hipLaunchKernelGGL(k2_sumsq<T>, dim3(1024), dim3(256), 0, s, m.dev, d.Nx, px, nz1, red_d);
+        FDTD_HIP(hipGetLastError());
+        std::vector<double> h(1024);
+        FDTD_HIP(hipMemcpyAsync(h.data(), red_d, 1024 * sizeof(double), hipMemcpyDeviceToHost, s));
+        FDTD_HIP(hipStreamSynchronize(s));
+        double acc = 0;
+        for (double v : h) acc += v;
+        *out = acc;
+        return FDTD_OK;
+    }
+
+    K2<T> args() {
+        K2<T> a;
+        a.Dy = Dy; a.Bx = Bx; a.Bz = Bz;
+        for (int f = 0; f < 3; ++f) { a.F1[f] = Fa[f]; a.F2[f] = Fb[f]; a.S1[f] = Sa[f]; a.S2[f] = Sb[f]; }
+        a.C1 = C[0]; a.C2 = C[1]; a.C3 = C[2];
+        for (int s = 0; s < 2; ++s) { a.ph_ey_z[s] = ph_z[0][s]; a.ph_mx_z[s] = ph_z[1][s]; a.ph_ey_x[s] = ph_x[0][s]; a.ph_mz_x[s] = ph_x[1][s]; }
+        a.tab = tab_d; a.xrow = xrow_d;
+        a.Nx = d.Nx; a.Nz = d.Nz; a.px = px; a.nz1 = nz1;
+        for (int ax = 0; ax < 2; ++ax) for (int s = 0; s < 2; ++s) a.np[ax][s] = np[ax][s];
+        a.xwn = xwn; a.xwp = xwp; a.xp0 = xp0;
+        a.iJ = d.i_Jy; a.kJ = d.k_Jy; a.src_on = 0; a.jy = (T)0;
+        a.dt = (T)d.dt; a.dtd[0] = (T)(d.dt / d.dx); a.dtd[1] = (T)(d.dt / d.dz); a.mu0 = (T)d.mu0; a.eps0 = (T)d.eps0;
+        a.chunk = chunk;
+        a.ntx = px / (kLanes * V);
+        a.nbx = (a.ntx + kWavesPerBlock - 1) / kWavesPerBlock;
+        a.nbz = (nz1 + chunk - 1) / chunk;
+        return a;
+    }
+    int step(int n0, int count, hipStream_t s) override {
+        for (int n = n0; n < n0 + count; ++n) {
+            K2<T> a = args();
+            a.src_on = (n >= 0 && n < (int)Jy.size()) ? 1 : 0;
+            a.jy = a.src_on ? a.dt * Jy[n] : (T)0;
+            const unsigned nblk = (unsigned)a.nbx * a.nbz;
+            timer.begin(0, s);
+            hipLaunchKernelGGL(k2_part_e<T>, dim3(nblk), dim3(256), 0, s, a);
+            timer.end(s);
+            FDTD_HIP(hipGetLastError());
+            std::swap(Fa[0], Fb[0]); std::swap(Sa[0], Sb[0]);       // new Ey/SEy now sit in the "current" slot
+            a = args();
+            timer.begin(1, s);
+            hipLaunchKernelGGL(k2_part_h<T>, dim3(nblk), dim3(256), 0, s, a);
+            timer.end(s);
+            FDTD_HIP(hipGetLastError());
+            for (int f = 1; f < 3; ++f) { std::swap(Fa[f], Fb[f]); std::swap(Sa[f], Sb[f]); }
+        }
+        return FDTD_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int fdtd2d_create(const fdtd2d_desc* d, fdtd2d_handle* out) {
+    if (!out) return fail(FDTD_ERR_ARG, "null output handle");
+    *out = nullptr;
+    if (!d) return fail(FDTD_ERR_ARG, "null descriptor");
+    if (d->struct_size != (int32_t)sizeof(fdtd2d_desc)) return fail(FDTD_ERR_ARG, "descriptor size %d, library expects %zu", d->struct_size, sizeof(fdtd2d_desc));
+    if (d->precision != 32 && d->precision != 64) return fail(FDTD_ERR_ARG, "precision must be 32 or 64");
+    if (d->Nx < 2 || d->Nz < 2) return fail(FDTD_ERR_ARG, "grid too small");
+    for (int q = 0; q < 4; ++q) if (d->n_pml[q] < 0 || d->n_pml[q] > kMaxLayers) return fail(FDTD_ERR_ARG, "CPML layer counts must be in [0,%d]", kMaxLayers);
+    if (d->n_pml[0] + d->n_pml[1] >= d->Nx || d->n_pml[2] + d->n_pml[3] >= d->Nz) return fail(FDTD_ERR_ARG, "CPML layers do not fit the grid");
+    // the reference silently skips a source outside [0,Nx]x[0,Nz] (FDTD2D.cpp:360); column Nx is the
+    // wall column this engine does not store, so a source there is refused instead of dropped
+    if (d->i_Jy == d->Nx) return fail(FDTD_ERR_ARG, "source column i_Jy = Nx lies on the wall");
+    if (!(d->dx > 0 && d->dz > 0 && d->dt > 0 && d->mu0 > 0 && d->eps0 > 0)) return fail(FDTD_ERR_ARG, "dx, dz, dt, mu0, eps0 must be positive");
+    if (d->device >= 0) FDTD_HIP(hipSetDevice(d->device));
+    int ndev = 0;
+    FDTD_HIP(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(FDTD_ERR_HIP, "no HIP device visible");
+    int rc;
+    if (d->precision == 32) { auto e = std::make_unique<Engine2<float>>(); if ((rc = e->init(*d))) return rc; *out = e.release(); }
+    else { auto e = std::make_unique<Engine2<double>>(); if ((rc = e->init(*d))) return rc; *out = e.release(); }
+    return FDTD_OK;
+}
+int fdtd2d_destroy(fdtd2d_handle h) { delete h; return FDTD_OK; }
+size_t fdtd2d_array_size(fdtd2d_handle h, int id) { return h ? h->array_size(id) : 0; }
+int fdtd2d_set_array(fdtd2d_handle h, int id, const double* host, size_t n) { return h ? h->set_array(id, host, n) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd2d_get_array(fdtd2d_handle h, int id, double* host, size_t n) { return h ? h->get_array(id, host, n) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd2d_step(fdtd2d_handle h, int n0, int count, void* stream) { return h ? h->step(n0, count, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd2d_sumsq(fdtd2d_handle h, int id, double* out, void* stream) { return (h && out) ? h->sumsq(id, out, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null argument"); }
+size_t fdtd2d_device_bytes(fdtd2d_handle h) { return h ? h->device_bytes() : 0; }
+int fdtd2d_kernel_timing(fdtd2d_handle h, int enable) { if (!h) return fail(FDTD_ERR_ARG, "null handle"); h->timer.enabled = enable != 0; return FDTD_OK; }
+int fdtd2d_kernel_time(fdtd2d_handle h, int kind, int* launches, double* total_ms) { return h ? h->timer.collect(kind, launches, total_ms) : fail(FDTD_ERR_ARG, "null handle"); }
+
+}  // extern "C"

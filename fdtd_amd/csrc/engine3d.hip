@@ -1,0 +1,542 @@
+// engine3d.hip -- host side of the 3-D engine: device state, array exchange, launches, C ABI.
+#include "kernels3d.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+namespace fdtd {
+
+// Order-independent 64-bit checksum term of one value at one canonical index.
+__host__ __device__ __forceinline__ uint64_t mix_term(uint64_t bits, uint64_t index) {
+    uint64_t z = bits + 0x9E3779B97F4A7C15ull * (index + 0x632BE59BD9B4E019ull);
+    z = (z ^ (z >> 32)) * 0xD6E8FEB86659FD93ull;
+    z = (z ^ (z >> 32)) * 0xD6E8FEB86659FD93ull;
+    return z ^ (z >> 32);
+}
+
+// Geometry of one stored component for the utility kernels.
+struct CompGeom {
+    int n[3];          // canonical extents
+    int Nx, px, ny1;   // stored columns, pitch, rows
+    int kl_lo, kl_hi;  // owned planes [kl_lo, kl_hi)
+    int zoff;
+};
+
+template <typename T>
+__global__ void k_fill_hash(T* arr, CompGeom g, uint64_t seed, uint32_t stream, double lo, double hi, int kl_all_lo, int kl_all_hi) {
+    // one thread per stored element of the planes [kl_all_lo, kl_all_hi) (owned + ghosts)
+    const size_t per_plane = (size_t)g.ny1 * g.px;
+    const size_t total = per_plane * (size_t)(kl_all_hi - kl_all_lo);
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int kl = kl_all_lo + (int)(t / per_plane);
+        const size_t r = t % per_plane;
+        const int j = (int)(r / g.px), i = (int)(r % g.px);
+        const int k = kl + g.zoff;
+        if (i >= g.Nx || i >= g.n[0] || j >= g.n[1] || k < 0 || k >= g.n[2]) continue;
+        const uint64_t canon = ((uint64_t)i * g.n[1] + j) * g.n[2] + k;
+        arr[(size_t)kl * per_plane + r] = (T)(lo + (hi - lo) * hash_unit(seed, stream, canon));
+    }
+}
+
+template <typename T> struct BitsOf;
+template <> struct BitsOf<float> { __host__ __device__ static uint64_t get(float v) { if (v == 0.0f) v = 0.0f; union { float f; uint32_t u; } x; x.f = v; return x.u; } };
+template <> struct BitsOf<double> { __host__ __device__ static uint64_t get(double v) { if (v == 0.0) v = 0.0; union { double f; uint64_t u; } x; x.f = v; return x.u; } };
+
+// out[0] += sum of squares (double), out[1] += checksum, over owned cells.
+template <typename T>
+__global__ void k_reduce(const T* arr, CompGeom g, double* sumsq_partial, unsigned long long* checksum) {
+    const size_t per_plane = (size_t)g.ny1 * g.px;
+    const size_t total = per_plane * (size_t)(g.kl_hi - g.kl_lo);
+    double s = 0;
+    unsigned long long c = 0;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int kl = g.kl_lo + (int)(t / per_plane);
+        const size_t r = t % per_plane;
+        const int j = (int)(r / g.px), i = (int)(r % g.px);
+        const int k = kl + g.zoff;
+        if (i >= g.Nx || i >= g.n[0] || j >= g.n[1] || k < 0 || k >= g.n[2]) continue;
+        const T v = arr[(size_t)kl * per_plane + r];
+        s += (double)v * (double)v;
+        if (v != (T)0) c += mix_term(BitsOf<T>::get(v), ((uint64_t)i * g.n[1] + j) * g.n[2] + k);
+    }
+    __shared__ double sh[256];
+    __shared__ unsigned long long shc[256];
+    sh[threadIdx.x] = s; shc[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sh[threadIdx.x] += sh[threadIdx.x + o]; shc[threadIdx.x] += shc[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { sumsq_partial[blockIdx.x] = sh[0]; atomicAdd(checksum, shc[0]); }
+}
+
+}  // namespace fdtd
+
+using namespace fdtd;
+
+struct fdtd3d_engine {
+    virtual ~fdtd3d_engine() {}
+    virtual size_t array_size(int id) = 0;
+    virtual int set_array(int id, const double* host, size_t n) = 0;
+    virtual int get_array(int id, double* host, size_t n) = 0;
+    virtual int fill_materials(uint64_t seed, double elo, double ehi, double mlo, double mhi) = 0;
+    virtual int half_e(int n, int part, hipStream_t s) = 0;
+    virtual int half_h(int part, hipStream_t s) = 0;
+    virtual int halo(int which, int comp, void** p, size_t* bytes) = 0;
+    virtual int reduce(int id, double* sumsq, uint64_t* checksum, hipStream_t s) = 0;
+    virtual size_t device_bytes() = 0;
+    fdtd3d_desc d;
+    KernelTimer timer;
+};
+
+namespace {
+
+template <typename T>
+struct Engine3 : fdtd3d_engine {
+    static constexpr int V = VecWidth<T>::V;
+    int px = 0, ny1 = 0, nzl = 0, nzp = 0, zoff = 0;
+    int np[3][2];
+    int xwn = 0, xwp = 0, xp0 = 0;
+    bool last_rank = false, full = true;
+    size_t plane = 0, fsize = 0, bytes = 0;
+    T* fld[18] = {nullptr};           // D E B H eps mu, three each (mu only if has_mu; E,H absent in LEAN)
+    T* phE[3][3][2];
+    T* phM[3][3][2];
+    size_t phSize[2][3][3][2];
+    T* tab_d = nullptr;
+    T* xrow_d = nullptr;
+    T* mag_d = nullptr;
+    double* red_d = nullptr;          // reduction scratch: 1024 partial sums + checksum word
+    std::vector<double> tab_h;        // [3][2][6][kMaxLayers], fp64 master copy
+    std::vector<T> wf;
+    int chunk = 16;
+    std::vector<void*> allocs;
+
+    ~Engine3() override {
+        for (void* p : allocs) (void)hipFree(p);
+        timer.release();
+    }
+
+    int dalloc(void** p, size_t nbytes, int fill_byte_pattern_zero = 1) {
+        if (nbytes == 0) { *p = nullptr; return FDTD_OK; }
+        FDTD_HIP(hipMalloc(p, nbytes));
+        allocs.push_back(*p);
+        bytes += nbytes;
+        if (fill_byte_pattern_zero) FDTD_HIP(hipMemset(*p, 0, nbytes));
+        return FDTD_OK;
+    }
+
+    int init(const fdtd3d_desc& dd) {
+        d = dd;
+        for (int a = 0; a < 3; ++a) for (int s = 0; s < 2; ++s) { np[a][s] = d.n_pml[a * 2 + s]; }
+        px = round_up(d.Nx, kRowAlign);
+        ny1 = d.Ny + 1;
+        nzl = d.z_hi - d.z_lo;
+        nzp = nzl + 2;
+        zoff = d.z_lo - 1;
+        last_rank = d.z_hi == d.Nz;
+        full = d.mode == FDTD3D_MODE_FULL;
+        plane = (size_t)ny1 * px;
+        fsize = plane * nzp;
+        xwn = np[0][0] > 0 ? round_up(np[0][0] + 1, 4) : 0;
+        xp0 = (d.Nx - np[0][1]) / 4 * 4;
+        xwp = np[0][1] > 0 ? round_up(d.Nx - xp0, 4) : 0;
+        if (const char* e = getenv("FDTD_Z_CHUNK")) { int c = atoi(e); if (c >= 1 && c <= 4096) chunk = c; }
+
+        int rc;
+        for (int f = 0; f < 6; ++f) for (int c = 0; c < 3; ++c) {
+            const int id = f * 3 + c;
+            fld[id] = nullptr;
+            if (f == 5 && !d.has_mu) continue;
+            if (!full && (f == 1 || f == 3)) continue;
+            // one row of slack behind every array: vector accesses of the last row may look one pack ahead
+            if ((rc = dalloc((void**)&fld[id], (fsize + px) * sizeof(T)))) return rc;
+            if (f >= 4) { if ((rc = fill_const(fld[id], fsize + px, (T)1))) return rc; }
+        }
+        for (int m = 0; m < 2; ++m) for (int c = 0; c < 3; ++c) for (int a = 0; a < 3; ++a) for (int s = 0; s < 2; ++s) {
+            T** slot = m ? &phM[c][a][s] : &phE[c][a][s];
+            *slot = nullptr;
+            phSize[m][c][a][s] = 0;
+            if (a == c || np[a][s] == 0) continue;
+            size_t n = 0;
+            if (a == 2) n = (size_t)np[2][s] * plane;
+            else if (a == 1) n = (size_t)nzp * np[1][s] * px;
+            else n = (size_t)nzp * ny1 * (s ? xwp : xwn);
+            phSize[m][c][a][s] = n;
+            if ((rc = dalloc((void**)slot, (n + px) * sizeof(T)))) return rc;
+        }
+        tab_h.assign((size_t)3 * 2 * 6 * kMaxLayers, 0.0);
+        if ((rc = dalloc((void**)&tab_d, tab_h.size() * sizeof(T)))) return rc;
+        if ((rc = dalloc((void**)&xrow_d, (size_t)6 * px * sizeof(T)))) return rc;
+        if ((rc = dalloc((void**)&mag_d, plane * sizeof(T)))) return rc;
+        if ((rc = dalloc((void**)&red_d, 1025 * sizeof(double)))) return rc;
+        wf.assign(d.n_wf > 0 ? d.n_wf : 0, (T)0);
+        return FDTD_OK;
+    }
+
+    int fill_const(T* p, size_t n, T v) {
+        std::vector<T> h(std::min<size_t>(n, (size_t)1 << 22), v);
+        for (size_t o = 0; o < n; o += h.size()) {
+            const size_t m = std::min(h.size(), n - o);
+            FDTD_HIP(hipMemcpy(p + o, h.data(), m * sizeof(T), hipMemcpyHostToDevice));
+        }
+        return FDTD_OK;
+    }
+
+    size_t device_bytes() override { return bytes; }
+
+    // ---- canonical <-> device index maps ------------------------------------------------
+    struct Map {
+        int n[3] = {0, 0, 0};     // canonical extents
+        T* dev = nullptr;
+        size_t dev_elems = 0;
+        int kind = -1;            // 0 field, 1 phi z, 2 phi y, 3 phi x, 4 mag
+        bool mag = false;
+        int c = 0, a = 0, s = 0;
+        size_t canon_size() const { return (size_t)n[0] * n[1] * n[2]; }
+    };
+
+    bool make_map(int id, Map& m) {
+        const int N[3] = {d.Nx, d.Ny, d.Nz};
+        if (id >= 0 && id < 18) {
+            const int f = id / 3, c = id % 3;
+            if (f == 5 && !d.has_mu) return false;
+            const bool electric = (f == 0 || f == 1 || f == 4);
+            for (int q = 0; q < 3; ++q) m.n[q] = electric ? N[q] + (q != c) : N[q] + (q == c);
+            m.dev = fld[id]; m.dev_elems = fsize; m.kind = 0; m.c = c;
+            return true;
+        }
+        const bool isE = id >= FDTD3D_PHI_E && id < FDTD3D_PHI_E + 18, isM = id >= FDTD3D_PHI_M && id < FDTD3D_PHI_M + 18;
+        if (isE || isM) {
+            const int r = id - (isM ? FDTD3D_PHI_M : FDTD3D_PHI_E);
+            m.s = r % 2; m.a = (r / 2) % 3; m.c = r / 6; m.mag = isM;
+            if (m.a == m.c) return false;
+            for (int q = 0; q < 3; ++q) m.n[q] = isM ? N[q] + (q == m.c) : N[q] + (q != m.c);
+            m.n[m.a] = np[m.a][m.s];
+            m.dev = isM ? phM[m.c][m.a][m.s] : phE[m.c][m.a][m.s];
+            m.dev_elems = phSize[isM][m.c][m.a][m.s];
+            m.kind = m.a == 2 ? 1 : (m.a == 1 ? 2 : 3);
+            return true;
+        }
+        if (id == FDTD3D_JX_MAG) { m.n[0] = d.Nx; m.n[1] = d.Ny + 1; m.n[2] = 1; m.dev = mag_d; m.dev_elems = plane; m.kind = 4; return true; }
+        return false;
+    }
+    // layer l of face (a,s) -> cell index along a (backward-difference terms start at 1)
+    int layer_cell(bool mag, int a, int s, int l) const {
+        const int N[3] = {d.Nx, d.Ny, d.Nz};
+        if (s) return N[a] - np[a][1] + l;
+        return mag ? l : 1 + l;
+    }
+    // device offset of canonical (p0,p1,p2), or -1 if this slab does not store it; owned tells
+    // whether the slab is the one that reports it on download.
+    long long dev_off(const Map& m, int p0, int p1, int p2, bool& owned) const {
+        owned = false;
+        auto own_k = [&](int k) { return (k >= d.z_lo && k < d.z_hi) || (last_rank && k == d.Nz); };
+        switch (m.kind) {
+            case 0: {
+                if (p0 >= d.Nx) return -1;
+                const int kl = p2 - zoff;
+                if (kl < 0 || kl >= nzp) return -1;
+                owned = own_k(p2);
+                return ((long long)kl * ny1 + p1) * px + p0;
+            }
+            case 1: {       // z face: canonical (i, j, l), device [l][j][i]
+                if (p0 >= d.Nx) return -1;
+                owned = own_k(layer_cell(m.mag, 2, m.s, p2));
+                return ((long long)p2 * ny1 + p1) * px + p0;
+            }
+            case 2: {       // y face: canonical (i, l, k), device [kl][l][i]
+                if (p0 >= d.Nx) return -1;
+                const int kl = p2 - zoff;
+                if (kl < 0 || kl >= nzp) return -1;
+                owned = own_k(p2);
+                return ((long long)kl * np[1][m.s] + p1) * px + p0;
+            }
+            case 3: {       // x face: canonical (l, j, k), device [kl][j][column - strip origin]
+                const int kl = p2 - zoff;
+                if (kl < 0 || kl >= nzp) return -1;
+                const int col = layer_cell(m.mag, 0, m.s, p0);
+                if (col < 0 || col >= d.Nx) return -1;
+                owned = own_k(p2);
+                return m.s ? ((long long)kl * ny1 + p1) * xwp + (col - xp0) : ((long long)kl * ny1 + p1) * xwn + col;
+            }
+            case 4: owned = true; return (long long)p1 * px + p0;
+        }
+        return -1;
+    }
+
+    size_t array_size(int id) override {
+        Map m;
+        if (make_map(id, m)) return m.canon_size();
+        if (id >= FDTD3D_TAB && id < FDTD3D_TAB + 36) return np[(id - FDTD3D_TAB) / 12][((id - FDTD3D_TAB) / 6) % 2];
+        if (id == FDTD3D_JX_WF) return wf.size();
+        return 0;
+    }
+
+    int upload_tables() {
+        std::vector<T> t(tab_h.size());
+        for (size_t q = 0; q < t.size(); ++q) t[q] = (T)tab_h[q];
+        FDTD_HIP(hipMemcpy(tab_d, t.data(), t.size() * sizeof(T), hipMemcpyHostToDevice));
+        // x-face rows expanded per column: kinds 0-2 for the backward-difference (D) zones,
+        // 3-5 for the forward-difference (B) zones
+        std::vector<T> xr((size_t)6 * px, (T)0);
+        auto tb = [&](int s, int kind, int l) { return (T)tab_h[((size_t)(0 * 2 + s) * 6 + kind) * kMaxLayers + l]; };
+        for (int i = 0; i < d.Nx; ++i) {
+            int l;
+            int z = zone_e(i, d.Nx, np[0][0], np[0][1], l);
+            if (z == Z_NEG || z == Z_POS) for (int q = 0; q < 3; ++q) xr[(size_t)q * px + i] = tb(z == Z_POS, q, l);
+            z = zone_h(i, d.Nx, np[0][0], np[0][1], true, l);
+            if (z == Z_NEG || z == Z_POS) for (int q = 3; q < 6; ++q) xr[(size_t)q * px + i] = tb(z == Z_POS, q, l);
+        }
+        FDTD_HIP(hipMemcpy(xrow_d, xr.data(), xr.size() * sizeof(T), hipMemcpyHostToDevice));
+        return FDTD_OK;
+    }
+
+    int set_array(int id, const double* host, size_t n) override {
+        if (n != array_size(id) || (n && !host)) return fail(FDTD_ERR_ARG, "set_array(%d): expected %zu values, got %zu", id, array_size(id), n);
+        if (id >= FDTD3D_TAB && id < FDTD3D_TAB + 36) {
+            const int r = id - FDTD3D_TAB;
+            for (size_t q = 0; q < n; ++q) tab_h[(size_t)r * kMaxLayers + q] = host[q];
+            return upload_tables();
+        }
+        if (id == FDTD3D_JX_WF) { for (size_t q = 0; q < n; ++q) wf[q] = (T)host[q]; return FDTD_OK; }
+        Map m;
+        if (!make_map(id, m)) return fail(FDTD_ERR_ARG, "set_array: unknown array id %d", id);
+        if (n == 0) return FDTD_OK;
+        if (!m.dev) return fail(FDTD_ERR_STATE, "set_array(%d): array is not resident in this storage mode", id);
+        std::vector<T> st(m.dev_elems);
+        FDTD_HIP(hipMemcpy(st.data(), m.dev, st.size() * sizeof(T), hipMemcpyDeviceToHost));
+        size_t o = 0;
+        for (int p0 = 0; p0 < m.n[0]; ++p0) for (int p1 = 0; p1 < m.n[1]; ++p1) for (int p2 = 0; p2 < m.n[2]; ++p2, ++o) {
+            bool owned;
+            const long long off = dev_off(m, p0, p1, p2, owned);
+            if (off >= 0) st[(size_t)off] = (T)host[o];
+        }
+        FDTD_HIP(hipMemcpy(m.dev, st.data(), st.size() * sizeof(T), hipMemcpyHostToDevice));
+        return FDTD_OK;
+    }
+
+    int get_array(int id, double* host, size_t n) override {
+        if (n != array_size(id) || (n && !host)) return fail(FDTD_ERR_ARG, "get_array(%d): expected %zu values, got %zu", id, array_size(id), n);
+        if (id >= FDTD3D_TAB && id < FDTD3D_TAB + 36) {
+            for (size_t q = 0; q < n; ++q) host[q] = tab_h[(size_t)(id - FDTD3D_TAB) * kMaxLayers + q];
+            return FDTD_OK;
+        }
+        if (id == FDTD3D_JX_WF) { for (size_t q = 0; q < n; ++q) host[q] = (double)wf[q]; return FDTD_OK; }
+        Map m;
+        if (!make_map(id, m)) return fail(FDTD_ERR_ARG, "get_array: unknown array id %d", id);
+        if (n == 0) return FDTD_OK;
+        if (!m.dev) return fail(FDTD_ERR_STATE, "get_array(%d): array is not resident in this storage mode", id);
+        FDTD_HIP(hipDeviceSynchronize());
+        std::vector<T> st(m.dev_elems);
+        FDTD_HIP(hipMemcpy(st.data(), m.dev, st.size() * sizeof(T), hipMemcpyDeviceToHost));
+        size_t o = 0;
+        for (int p0 = 0; p0 < m.n[0]; ++p0) for (int p1 = 0; p1 < m.n[1]; ++p1) for (int p2 = 0; p2 < m.n[2]; ++p2, ++o) {
+            bool owned;
+            const long long off = dev_off(m, p0, p1, p2, owned);
+            if (off >= 0) { if (owned) host[o] = (double)st[(size_t)off]; }
+            else if (m.kind == 0 && p0 >= d.Nx) host[o] = 0.0;          // unstored wall column
+        }
+        return FDTD_OK;
+    }
+
+    CompGeom geom(int id, bool owned_only) {
+        CompGeom g;
+        Map m; make_map(id, m);
+        for (int q = 0; q < 3; ++q) g.n[q] = m.n[q];
+        g.Nx = d.Nx; g.px = px; g.ny1 = ny1; g.zoff = zoff;
+        g.kl_lo = owned_only ? 1 : 0;
+        g.kl_hi = owned_only ? (last_rank ? nzp : nzp - 1) : nzp;
+        return g;
+    }
+
+    int fill_materials(uint64_t seed, double elo, double ehi, double mlo, double mhi) override {
+        for (int c = 0; c < 3; ++c) {
+            hipLaunchKernelGGL(k_fill_hash<T>, dim3(2048), dim3(256), 0, 0, fld[12 + c], geom(12 + c, false), seed, (uint32_t)c, elo, ehi, 0, nzp);
+            if (d.has_mu) hipLaunchKernelGGL(k_fill_hash<T>, dim3(2048), dim3(256), 0, 0, fld[15 + c], geom(15 + c, false), seed, (uint32_t)(3 + c), mlo, mhi, 0, nzp);
+        }
+        FDTD_HIP(hipGetLastError());
+        FDTD_HIP(hipDeviceSynchronize());
+        return FDTD_OK;
+    }
+
+    int reduce(int id, double* sumsq, uint64_t* checksum, hipStream_t s) override {
+        if (id < 0 || id >= 18 || !fld[id]) return fail(FDTD_ERR_ARG, "reduce: array %d is not a resident field", id);
+        FDTD_HIP(hipMemsetAsync(red_d, 0, 1025 * sizeof(double), s));
+        hipLaunchKernelGGL(k_reduce<T>, dim3(1024), dim3(256), 0, s, fld[id], geom(id, true), red_d, (unsigned long long*)(red_d + 1024));
+        FDTD_HIP(hipGetLastError());
+        std::vector<double> h(1025);
+        FDTD_HIP(hipMemcpyAsync(h.data(), red_d, 1025 * sizeof(double), hipMemcpyDeviceToHost, s));
+        FDTD_HIP(hipStreamSynchronize(s));
+        double acc = 0;
+        for (int q = 0; q < 1024; ++q) acc += h[q];
+        if (sumsq) *sumsq = acc;
+        if (checksum) std::memcpy(checksum, &h[1024], sizeof(uint64_t));
+        return FDTD_OK;
+    }
+
+    // ---- launches -----------------------------------------------------------------------
+    K3<T> args() {
+        K3<T> a;
+        for (int c = 0; c < 3; ++c) {
+            a.D[c] = fld[c]; a.E[c] = fld[3 + c]; a.B[c] = fld[6 + c]; a.H[c] = fld[9 + c];
+            a.eps[c] = fld[12 + c]; a.mu[c] = fld[15 + c];
+            for (int ax = 0; ax < 3; ++ax) for (int s = 0; s < 2; ++s) { a.phE[c][ax][s] = phE[c][ax][s]; a.phM[c][ax][s] = phM[c][ax][s]; }
+        }
+        a.tab = tab_d; a.xrow = xrow_d; a.mag = mag_d;
+        a.Nx = d.Nx; a.Ny = d.Ny; a.Nz = d.Nz; a.px = px; a.ny1 = ny1; a.nzp = nzp; a.zoff = zoff;
+        for (int ax = 0; ax < 3; ++ax) for (int s = 0; s < 2; ++s) a.np[ax][s] = np[ax][s];
+        a.xwn = xwn; a.xwp = xwp; a.xp0 = xp0;
+        a.kJ = d.k_Jx; a.src_on = 0; a.jx = (T)0;
+        a.dt = (T)d.dt; a.dtd[0] = (T)(d.dt / d.dx); a.dtd[1] = (T)(d.dt / d.dy); a.dtd[2] = (T)(d.dt / d.dz); a.mu0 = (T)d.mu0;
+        a.nbx = px / (kLanes * V); a.nby = (ny1 + kWavesPerBlock - 1) / kWavesPerBlock;
+        a.chunk = chunk;
+        return a;
+    }
+    // planes [kl0,kl1) of a part; E-half edge = lowest owned plane, H-half edge = highest owned
+    // cell layer (the closing wall plane of the last slab counts as interior).
+    bool part_range(bool eh, int part, int& kl0, int& kl1) const {
+        const int lo = 1, hi = last_rank ? nzp : nzp - 1;   // owned planes [lo,hi)
+        const int top_layer = nzl;                           // plane of cell layer z_hi-1
+        if (part == FDTD3D_PART_ALL) { kl0 = lo; kl1 = hi; return true; }
+        if (eh) {
+            if (part == FDTD3D_PART_EDGE) { kl0 = lo; kl1 = lo + 1; return true; }
+            if (part == FDTD3D_PART_INTERIOR) { kl0 = lo + 1; kl1 = hi; return true; }
+        } else {
+            if (part == FDTD3D_PART_EDGE) { kl0 = top_layer; kl1 = top_layer + 1; return true; }
+        }
+        return false;
+    }
+    template <typename Kern>
+    int launch(Kern kern, K3<T> a, int kl0, int kl1, int kind, hipStream_t s) {
+        if (kl1 <= kl0) return FDTD_OK;
+        a.kl0 = kl0; a.kl1 = kl1;
+        a.nbz = (kl1 - kl0 + a.chunk - 1) / a.chunk;
+        const unsigned nblk = (unsigned)a.nbx * a.nby * a.nbz;
+        timer.begin(kind, s);
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), 0, s, a);
+        timer.end(s);
+        FDTD_HIP(hipGetLastError());
+        return FDTD_OK;
+    }
+    int half_e(int n, int part, hipStream_t s) override {
+        K3<T> a = args();
+        a.src_on = (n >= 0 && n < (int)wf.size()) ? 1 : 0;
+        a.jx = a.src_on ? a.dt * wf[n] : (T)0;      // product formed first, as FDTD3D.cpp:482
+        int kl0, kl1;
+        if (!part_range(true, part, kl0, kl1)) return fail(FDTD_ERR_ARG, "half_e: bad part %d", part);
+        return launch(k3_half_e<T>, a, kl0, kl1, 0, s);
+    }
+    int half_h(int part, hipStream_t s) override {
+        K3<T> a = args();
+        int kl0, kl1;
+        if (part == FDTD3D_PART_INTERIOR) {
+            // everything except the highest owned cell layer: the planes below it, and the closing plane above it
+            int rc = d.has_mu ? launch(k3_half_h<T, true>, a, 1, nzl, 1, s) : launch(k3_half_h<T, false>, a, 1, nzl, 1, s);
+            if (rc || !last_rank) return rc;
+            return d.has_mu ? launch(k3_half_h<T, true>, a, nzl + 1, nzp, 1, s) : launch(k3_half_h<T, false>, a, nzl + 1, nzp, 1, s);
+        }
+        if (!part_range(false, part, kl0, kl1)) return fail(FDTD_ERR_ARG, "half_h: bad part %d", part);
+        return d.has_mu ? launch(k3_half_h<T, true>, a, kl0, kl1, 1, s) : launch(k3_half_h<T, false>, a, kl0, kl1, 1, s);
+    }
+
+    int halo(int which, int comp, void** p, size_t* nbytes) override {
+        if (comp < 0 || comp > 1) return fail(FDTD_ERR_ARG, "halo: comp must be 0 or 1");
+        T* base = nullptr;
+        int kl = 0;
+        switch (which) {
+            case FDTD3D_HALO_SEND_UP: base = fld[(full ? 9 : 6) + comp]; kl = nzl; break;       // H (or B), layer z_hi-1
+            case FDTD3D_HALO_RECV_LO: base = fld[(full ? 9 : 6) + comp]; kl = 0; break;         // ghost z_lo-1
+            case FDTD3D_HALO_SEND_DOWN: base = fld[(full ? 3 : 0) + comp]; kl = 1; break;       // E (or D), layer z_lo
+            case FDTD3D_HALO_RECV_HI: base = fld[(full ? 3 : 0) + comp]; kl = nzl + 1; break;   // ghost z_hi
+            default: return fail(FDTD_ERR_ARG, "halo: bad selector %d", which);
+        }
+        *p = base + (size_t)kl * plane;
+        *nbytes = plane * sizeof(T);
+        return FDTD_OK;
+    }
+};
+
+int check_desc(const fdtd3d_desc* d) {
+    if (!d) return fail(FDTD_ERR_ARG, "null descriptor");
+    if (d->struct_size != (int32_t)sizeof(fdtd3d_desc)) return fail(FDTD_ERR_ARG, "descriptor size %d, library expects %zu", d->struct_size, sizeof(fdtd3d_desc));
+    if (d->precision != 32 && d->precision != 64) return fail(FDTD_ERR_ARG, "precision must be 32 or 64");
+    const int N[3] = {d->Nx, d->Ny, d->Nz};
+    for (int a = 0; a < 3; ++a) {
+        if (N[a] < 2) return fail(FDTD_ERR_ARG, "grid extent %d along axis %d is too small", N[a], a);
+        const int nn = d->n_pml[2 * a], np = d->n_pml[2 * a + 1];
+        if (nn < 0 || np < 0 || nn > kMaxLayers || np > kMaxLayers) return fail(FDTD_ERR_ARG, "CPML layer counts must be in [0,%d]", kMaxLayers);
+        // the reference's low, middle and high sweeps only tile the axis without overlap under this condition
+        if (nn + np >= N[a]) return fail(FDTD_ERR_ARG, "CPML layers (%d+%d) do not fit %d cells along axis %d", nn, np, N[a], a);
+    }
+    if (d->z_lo < 0 || d->z_hi > d->Nz || d->z_lo >= d->z_hi) return fail(FDTD_ERR_ARG, "bad slab [%d,%d) of %d layers", d->z_lo, d->z_hi, d->Nz);
+    if (d->k_Jx < 0 || d->k_Jx > d->Nz) return fail(FDTD_ERR_ARG, "source plane %d outside [0,%d]", d->k_Jx, d->Nz);
+    if (d->mode != FDTD3D_MODE_FULL && d->mode != FDTD3D_MODE_LEAN) return fail(FDTD_ERR_ARG, "unknown storage mode %d", d->mode);
+    if (!(d->dx > 0 && d->dy > 0 && d->dz > 0 && d->dt > 0 && d->mu0 > 0)) return fail(FDTD_ERR_ARG, "dx, dy, dz, dt, mu0 must be positive");
+    return FDTD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fdtd3d_create(const fdtd3d_desc* desc, fdtd3d_handle* out) {
+    if (!out) return fail(FDTD_ERR_ARG, "null output handle");
+    *out = nullptr;
+    if (int rc = check_desc(desc)) return rc;
+    if (desc->mode == FDTD3D_MODE_LEAN) return fail(FDTD_ERR_ARG, "lean storage mode is not available in this build");
+    if (desc->device >= 0) FDTD_HIP(hipSetDevice(desc->device));
+    int ndev = 0;
+    FDTD_HIP(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(FDTD_ERR_HIP, "no HIP device visible");
+    int rc;
+    if (desc->precision == 32) {
+        auto e = std::make_unique<Engine3<float>>();
+        if ((rc = e->init(*desc))) return rc;
+        *out = e.release();
+    } else {
+        auto e = std::make_unique<Engine3<double>>();
+        if ((rc = e->init(*desc))) return rc;
+        *out = e.release();
+    }
+    return FDTD_OK;
+}
+int fdtd3d_destroy(fdtd3d_handle h) { delete h; return FDTD_OK; }
+size_t fdtd3d_array_size(fdtd3d_handle h, int id) { return h ? h->array_size(id) : 0; }
+int fdtd3d_set_array(fdtd3d_handle h, int id, const double* host, size_t n) { return h ? h->set_array(id, host, n) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_get_array(fdtd3d_handle h, int id, double* host, size_t n) { return h ? h->get_array(id, host, n) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_fill_materials(fdtd3d_handle h, uint64_t seed, double elo, double ehi, double mlo, double mhi) {
+    return h ? h->fill_materials(seed, elo, ehi, mlo, mhi) : fail(FDTD_ERR_ARG, "null handle");
+}
+int fdtd3d_step(fdtd3d_handle h, int n0, int count, void* stream) {
+    if (!h) return fail(FDTD_ERR_ARG, "null handle");
+    if (h->d.z_lo != 0 || h->d.z_hi != h->d.Nz) return fail(FDTD_ERR_STATE, "fdtd3d_step needs the whole grid on this device; slab drivers use fdtd3d_half_e / fdtd3d_half_h");
+    for (int n = n0; n < n0 + count; ++n) {
+        if (int rc = h->half_e(n, FDTD3D_PART_ALL, (hipStream_t)stream)) return rc;
+        if (int rc = h->half_h(FDTD3D_PART_ALL, (hipStream_t)stream)) return rc;
+    }
+    return FDTD_OK;
+}
+int fdtd3d_half_e(fdtd3d_handle h, int n, int part, void* stream) { return h ? h->half_e(n, part, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_half_h(fdtd3d_handle h, int part, void* stream) { return h ? h->half_h(part, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_halo(fdtd3d_handle h, int which, int comp, void** p, size_t* bytes) {
+    if (!h || !p || !bytes) return fail(FDTD_ERR_ARG, "null argument");
+    return h->halo(which, comp, p, bytes);
+}
+int fdtd3d_sumsq(fdtd3d_handle h, int id, double* out, void* stream) { return h ? h->reduce(id, out, nullptr, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_checksum(fdtd3d_handle h, int id, uint64_t* out, void* stream) { return h ? h->reduce(id, nullptr, out, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
+size_t fdtd3d_device_bytes(fdtd3d_handle h) { return h ? h->device_bytes() : 0; }
+int fdtd3d_kernel_timing(fdtd3d_handle h, int enable) {
+    if (!h) return fail(FDTD_ERR_ARG, "null handle");
+    h->timer.enabled = enable != 0;
+    return FDTD_OK;
+}
+int fdtd3d_kernel_time(fdtd3d_handle h, int kind, int* launches, double* total_ms) {
+    if (!h) return fail(FDTD_ERR_ARG, "null handle");
+    return h->timer.collect(kind, launches, total_ms);
+}
+
+}  // extern "C"

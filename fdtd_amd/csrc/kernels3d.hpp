@@ -1,0 +1,366 @@
+// kernels3d.hpp -- gfx950 kernels of the 3-D Yee update (E-half and H-half).
+//
+// Replaces FDTD3D::updateE / applySource / updateElectricMaterialRelations and
+// FDTD3D::updateH / updateMagneticMaterialRelations (fdtd3d/src/FDTD3D.cpp:480-1021).
+//
+// Device layout of every field component: [plane kl][row j][i], i unit-stride, rows padded to a
+// multiple of 256 elements, Ny+1 rows, (owned layers + 2) planes -- plane 0 is the ghost layer
+// below the slab, the last plane the ghost layer above it (or the closing wall layer k = Nz).
+// Components whose x extent is Nx+1 do not store i = Nx: neither half step ever writes that
+// wall column (all sweeps over those components stop at Nx-1), so it is identically zero.
+//
+// Work decomposition: a 256-thread workgroup owns an x tile of 64 lanes x 16 bytes and four
+// consecutive rows (one wave per row) and marches through a chunk of planes.  The z-neighbour
+// needed by the z derivative travels in registers from one plane iteration to the next; the
+// y-neighbour row is the row a sibling wave is loading at the same moment (L1/L2 hit); the
+// x-neighbour is one cross-lane shift.  Every field word is therefore fetched from HBM once
+// per half step.  All three axis terms, the source and the constitutive division are applied
+// in one pass, in the reference's per-cell order of floating-point operations.
+#pragma once
+#include "common.hpp"
+
+namespace fdtd {
+
+template <typename T>
+struct K3 {
+    T* D[3];
+    T* E[3];
+    T* B[3];
+    T* H[3];
+    const T* eps[3];
+    const T* mu[3];
+    T* phE[3][3][2];   // [component][axis][side]
+    T* phM[3][3][2];
+    const T* tab;      // [axis][side][kind 6][kMaxLayers]
+    const T* xrow;     // [kind 6][px]: x-face coefficients expanded per i
+    const T* mag;      // [ny1][px]
+    int Nx, Ny, Nz;    // global cell counts
+    int px, ny1, nzp;  // row pitch, rows per plane, planes stored
+    int zoff;          // global k = kl + zoff
+    int np[3][2];
+    int xwn, xwp, xp0; // x-face auxiliary strips: widths and first column of the high strip
+    int kJ;            // global source plane
+    int src_on;
+    T jx;              // dt * wf[n]
+    T dt, dtd[3], mu0;
+    int kl0, kl1;      // planes to process [kl0, kl1)
+    int chunk;         // planes per workgroup
+    int nbx, nby, nbz;
+};
+
+template <typename T, int V>
+__device__ __forceinline__ T left_of(const Pack<T, V>& x, const T* p, int i0, int lane) {
+    T l = __shfl_up(x.v[V - 1], 1);
+    if (lane == 0) l = (i0 > 0) ? p[-1] : (T)0;
+    return l;
+}
+template <typename T, int V>
+__device__ __forceinline__ T right_of(const Pack<T, V>& x, const T* p, int i0, int lane, int px) {
+    T r = __shfl_down(x.v[0], 1);
+    if (lane == kLanes - 1) r = (i0 + V < px) ? p[V] : (T)0;
+    return r;
+}
+template <typename T, int V>
+__device__ __forceinline__ Pack<T, V> diff(const Pack<T, V>& a, const Pack<T, V>& b) {
+    Pack<T, V> r;
+#pragma unroll
+    for (int e = 0; e < V; ++e) r.v[e] = a.v[e] - b.v[e];
+    return r;
+}
+// a[e] - a[e-1]
+template <typename T, int V>
+__device__ __forceinline__ Pack<T, V> diff_back_x(const Pack<T, V>& a, T left) {
+    Pack<T, V> r;
+    r.v[0] = a.v[0] - left;
+#pragma unroll
+    for (int e = 1; e < V; ++e) r.v[e] = a.v[e] - a.v[e - 1];
+    return r;
+}
+// a[e+1] - a[e]
+template <typename T, int V>
+__device__ __forceinline__ Pack<T, V> diff_fwd_x(const Pack<T, V>& a, T right) {
+    Pack<T, V> r;
+#pragma unroll
+    for (int e = 0; e < V - 1; ++e) r.v[e] = a.v[e + 1] - a.v[e];
+    r.v[V - 1] = right - a.v[V - 1];
+    return r;
+}
+
+// Plain update: d +- (dt/d) * curl   (FDTD3D.cpp:572-573 pattern)
+template <int SIGN, typename T, int V>
+__device__ __forceinline__ void apply_mid(Pack<T, V>& d, const Pack<T, V>& curl, unsigned mask, T c) {
+#pragma unroll
+    for (int e = 0; e < V; ++e)
+        if (mask & (1u << e)) {
+            const T v = c * curl.v[e];
+            d.v[e] = SIGN > 0 ? d.v[e] + v : d.v[e] - v;
+        }
+}
+// CPML layer: phi = b*phi + a*curl;  d +- (C*curl + dt*phi)   (FDTD3D.cpp:545-548 pattern)
+template <int SIGN, typename T, int V>
+__device__ __forceinline__ void apply_pml(Pack<T, V>& d, const Pack<T, V>& curl, unsigned mask, T b, T a, T C, T dt, T* phi) {
+    Pack<T, V> ph = ldv<T, V>(phi);
+#pragma unroll
+    for (int e = 0; e < V; ++e)
+        if (mask & (1u << e)) {
+            const T p = b * ph.v[e] + a * curl.v[e];
+            ph.v[e] = p;
+            const T v = C * curl.v[e] + dt * p;
+            d.v[e] = SIGN > 0 ? d.v[e] + v : d.v[e] - v;
+        }
+    stv<T, V>(phi, ph);
+}
+// Term along an axis whose zone is the same for the whole wave (y: one row per wave, z: one
+// plane per iteration).  `face` points at the six tables of side 0 of that axis.
+template <int SIGN, typename T, int V>
+__device__ __forceinline__ void apply_uniform(Pack<T, V>& d, const Pack<T, V>& curl, unsigned mask, int zone, int l,
+                                              const T* __restrict__ face, int kb, T cmid, T dt, T* phi_n, T* phi_p) {
+    if (mask == 0u || zone == Z_NONE) return;
+    if (zone == Z_MID) { apply_mid<SIGN, T, V>(d, curl, mask, cmid); return; }
+    const T* t = face + (zone == Z_POS ? 6 * kMaxLayers : 0) + kb * kMaxLayers + l;
+    apply_pml<SIGN, T, V>(d, curl, mask, t[0], t[kMaxLayers], t[2 * kMaxLayers], dt, zone == Z_POS ? phi_p : phi_n);
+}
+// Term along x: the zone changes from element to element.  Coefficients come from rows expanded
+// per column; the auxiliary strips are only touched by lanes that overlap them.
+// OPEN_SKIP selects the 3-D forward-difference rule that leaves the last cell alone when the high
+// face has no CPML (zone_h); the 2-D solver does not have it.
+template <int SIGN, bool HTYPE, bool OPEN_SKIP, typename T, int V>
+__device__ __forceinline__ void apply_x(Pack<T, V>& d, const Pack<T, V>& curl, unsigned mask, int i0, int Nx, int nn, int np,
+                                        const T* __restrict__ xrow, int px, T cmid, T dt, T* phi_n, T* phi_p) {
+    if (mask == 0u) return;
+    const bool on_n = phi_n != nullptr, on_p = phi_p != nullptr;
+    Pack<T, V> pn = zero_pack<T, V>(), pp = zero_pack<T, V>(), b = zero_pack<T, V>(), a = zero_pack<T, V>(), C = zero_pack<T, V>();
+    if (on_n || on_p) {
+        const T* r = xrow + (HTYPE ? 3 : 0) * (size_t)px + i0;
+        b = ldv<T, V>(r); a = ldv<T, V>(r + px); C = ldv<T, V>(r + 2 * (size_t)px);
+        if (on_n) pn = ldv<T, V>(phi_n);
+        if (on_p) pp = ldv<T, V>(phi_p);
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e)
+        if (mask & (1u << e)) {
+            int l;
+            const int z = HTYPE ? zone_h(i0 + e, Nx, nn, np, OPEN_SKIP, l) : zone_e(i0 + e, Nx, nn, np, l);
+            if (z == Z_MID) {
+                const T v = cmid * curl.v[e];
+                d.v[e] = SIGN > 0 ? d.v[e] + v : d.v[e] - v;
+            } else if (z == Z_NEG || z == Z_POS) {
+                const T old = (z == Z_NEG) ? pn.v[e] : pp.v[e];
+                const T p = b.v[e] * old + a.v[e] * curl.v[e];
+                if (z == Z_NEG) pn.v[e] = p; else pp.v[e] = p;
+                const T v = C.v[e] * curl.v[e] + dt * p;
+                d.v[e] = SIGN > 0 ? d.v[e] + v : d.v[e] - v;
+            }
+        }
+    if (on_n) stv<T, V>(phi_n, pn);
+    if (on_p) stv<T, V>(phi_p, pp);
+}
+
+template <typename T, int V>
+__device__ __forceinline__ Pack<T, V> divide(const Pack<T, V>& n, const Pack<T, V>& d) {
+    Pack<T, V> r;
+#pragma unroll
+    for (int e = 0; e < V; ++e) r.v[e] = n.v[e] / d.v[e];
+    return r;
+}
+template <typename T, int V>
+__device__ __forceinline__ Pack<T, V> divide(const Pack<T, V>& n, T d) {
+    Pack<T, V> r;
+#pragma unroll
+    for (int e = 0; e < V; ++e) r.v[e] = n.v[e] / d;
+    return r;
+}
+
+template <typename T>
+struct Tile3 {
+    int lane, i0, j, klb, kle;
+    bool ok;
+    unsigned m_lt, m_in;   // element masks: i < Nx ; 1 <= i < Nx
+    bool lane_n, lane_p;   // lane overlaps the low / high x auxiliary strip
+};
+template <typename T>
+__device__ __forceinline__ Tile3<T> decode_tile(const K3<T>& a) {
+    constexpr int V = VecWidth<T>::V;
+    Tile3<T> t;
+    t.lane = threadIdx.x & (kLanes - 1);
+    const int w = threadIdx.x >> 6;
+    unsigned bid = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int bx = bid % a.nbx; bid /= a.nbx;
+    const int by = bid % a.nby;
+    const int bz = bid / a.nby;
+    t.i0 = (bx * kLanes + t.lane) * V;
+    t.j = by * kWavesPerBlock + w;
+    t.klb = a.kl0 + bz * a.chunk;
+    t.kle = min(t.klb + a.chunk, a.kl1);
+    t.ok = t.j < a.ny1;
+    t.m_lt = 0; t.m_in = 0;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        const int i = t.i0 + e;
+        if (i < a.Nx) t.m_lt |= 1u << e;
+        if (i >= 1 && i < a.Nx) t.m_in |= 1u << e;
+    }
+    t.lane_n = a.np[0][0] > 0 && t.i0 < a.xwn;
+    t.lane_p = a.np[0][1] > 0 && t.i0 >= a.xp0 && t.i0 < a.xp0 + a.xwp;
+    return t;
+}
+
+// ------------------------------------------------------------------ E-half --
+// D += curl H (CPML folded in), Dx += dt*wf[n]*mag on the source plane, E = D/eps.
+template <typename T>
+__global__ void __launch_bounds__(256) k3_half_e(const K3<T> a) {
+    constexpr int V = VecWidth<T>::V;
+    using P = Pack<T, V>;
+    const Tile3<T> t = decode_tile(a);
+    if (!t.ok) return;                       // whole wave leaves: one row per wave
+    const int j = t.j, i0 = t.i0, lane = t.lane;
+    const size_t sz = (size_t)a.ny1 * a.px;
+    const int Nx = a.Nx, Ny = a.Ny, Nz = a.Nz, px = a.px;
+    const T* __restrict__ Hx = a.H[0]; const T* __restrict__ Hy = a.H[1]; const T* __restrict__ Hz = a.H[2];
+
+    int ly;
+    const int zy = zone_e(j, Ny, a.np[1][0], a.np[1][1], ly);
+    const T* face_y = a.tab + (size_t)(1 * 2) * 6 * kMaxLayers;
+    const T* face_z = a.tab + (size_t)(2 * 2) * 6 * kMaxLayers;
+    const bool row_lt = j < Ny, row_in = j >= 1 && j < Ny;
+
+    size_t idx = ((size_t)t.klb * a.ny1 + j) * px + i0;
+    P hx_km = zero_pack<T, V>(), hy_km = zero_pack<T, V>();
+    if (t.klb + a.zoff >= 1) { hx_km = ldv<T, V>(Hx + idx - sz); hy_km = ldv<T, V>(Hy + idx - sz); }
+
+    for (int kl = t.klb; kl < t.kle; ++kl, idx += sz) {
+        const int k = kl + a.zoff;
+        int lk;
+        const int zk = zone_e(k, Nz, a.np[2][0], a.np[2][1], lk);
+        const bool pl_lt = k < Nz, pl_in = k >= 1 && k < Nz;
+
+        const P hx = ldv<T, V>(Hx + idx), hy = ldv<T, V>(Hy + idx), hz = ldv<T, V>(Hz + idx);
+        P hx_jm = zero_pack<T, V>(), hz_jm = zero_pack<T, V>();
+        if (j >= 1) { hx_jm = ldv<T, V>(Hx + idx - px); hz_jm = ldv<T, V>(Hz + idx - px); }
+        const T hy_l = left_of<T, V>(hy, Hy + idx, i0, lane);
+        const T hz_l = left_of<T, V>(hz, Hz + idx, i0, lane);
+
+        const size_t row_n = ((size_t)kl * a.ny1 + j) * a.xwn + i0;
+        const size_t row_p = ((size_t)kl * a.ny1 + j) * a.xwp + (i0 - a.xp0);
+
+        // ---- Dx: -dHy/dz (rows 0..Ny-1), then +dHz/dy (planes 1..Nz-1), then the source
+        {
+            P d = ldv<T, V>(a.D[0] + idx);
+            apply_uniform<-1, T, V>(d, diff<T, V>(hy, hy_km), row_lt ? t.m_lt : 0u, zk, lk, face_z, 0, a.dtd[2], a.dt,
+                                    a.phE[0][2][0] + ((size_t)lk * a.ny1 + j) * px + i0,
+                                    a.phE[0][2][1] + ((size_t)lk * a.ny1 + j) * px + i0);
+            apply_uniform<+1, T, V>(d, diff<T, V>(hz, hz_jm), pl_in ? t.m_lt : 0u, zy, ly, face_y, 0, a.dtd[1], a.dt,
+                                    a.phE[0][1][0] + ((size_t)kl * a.np[1][0] + ly) * px + i0,
+                                    a.phE[0][1][1] + ((size_t)kl * a.np[1][1] + ly) * px + i0);
+            if (a.src_on && k == a.kJ) {
+                const P m = ldv<T, V>(a.mag + (size_t)j * px + i0);
+#pragma unroll
+                for (int e = 0; e < V; ++e) if (t.m_lt & (1u << e)) d.v[e] = d.v[e] + a.jx * m.v[e];
+            }
+            stv<T, V>(a.D[0] + idx, d);
+            stv<T, V>(a.E[0] + idx, divide<T, V>(d, ldv<T, V>(a.eps[0] + idx)));
+        }
+        // ---- Dy: +dHx/dz (columns 1..Nx-1), then -dHz/dx (planes 1..Nz-1)
+        if (row_lt) {
+            P d = ldv<T, V>(a.D[1] + idx);
+            apply_uniform<+1, T, V>(d, diff<T, V>(hx, hx_km), t.m_in, zk, lk, face_z, 0, a.dtd[2], a.dt,
+                                    a.phE[1][2][0] + ((size_t)lk * a.ny1 + j) * px + i0,
+                                    a.phE[1][2][1] + ((size_t)lk * a.ny1 + j) * px + i0);
+            apply_x<-1, false, true, T, V>(d, diff_back_x<T, V>(hz, hz_l), pl_in ? t.m_lt : 0u, i0, Nx, a.np[0][0], a.np[0][1], a.xrow, px,
+                                     a.dtd[0], a.dt, t.lane_n ? a.phE[1][0][0] + row_n : nullptr, t.lane_p ? a.phE[1][0][1] + row_p : nullptr);
+            stv<T, V>(a.D[1] + idx, d);
+            stv<T, V>(a.E[1] + idx, divide<T, V>(d, ldv<T, V>(a.eps[1] + idx)));
+        }
+        // ---- Dz: +dHy/dx (rows 1..Ny-1), then -dHx/dy (columns 1..Nx-1); planes 0..Nz-1
+        if (pl_lt) {
+            P d = ldv<T, V>(a.D[2] + idx);
+            apply_x<+1, false, true, T, V>(d, diff_back_x<T, V>(hy, hy_l), row_in ? t.m_lt : 0u, i0, Nx, a.np[0][0], a.np[0][1], a.xrow, px,
+                                     a.dtd[0], a.dt, t.lane_n ? a.phE[2][0][0] + row_n : nullptr, t.lane_p ? a.phE[2][0][1] + row_p : nullptr);
+            apply_uniform<-1, T, V>(d, diff<T, V>(hx, hx_jm), t.m_in, zy, ly, face_y, 0, a.dtd[1], a.dt,
+                                    a.phE[2][1][0] + ((size_t)kl * a.np[1][0] + ly) * px + i0,
+                                    a.phE[2][1][1] + ((size_t)kl * a.np[1][1] + ly) * px + i0);
+            stv<T, V>(a.D[2] + idx, d);
+            stv<T, V>(a.E[2] + idx, divide<T, V>(d, ldv<T, V>(a.eps[2] + idx)));
+        }
+        hx_km = hx; hy_km = hy;
+    }
+}
+
+// ------------------------------------------------------------------ H-half --
+// B -= curl E (CPML folded in), H = B/mu0 (or B/mu).
+template <typename T, bool MU>
+__global__ void __launch_bounds__(256) k3_half_h(const K3<T> a) {
+    constexpr int V = VecWidth<T>::V;
+    using P = Pack<T, V>;
+    const Tile3<T> t = decode_tile(a);
+    if (!t.ok) return;
+    const int j = t.j, i0 = t.i0, lane = t.lane;
+    const size_t sz = (size_t)a.ny1 * a.px;
+    const int Nx = a.Nx, Ny = a.Ny, Nz = a.Nz, px = a.px;
+    const T* __restrict__ Ex = a.E[0]; const T* __restrict__ Ey = a.E[1]; const T* __restrict__ Ez = a.E[2];
+
+    int ly;
+    const int zy = zone_h(j, Ny, a.np[1][0], a.np[1][1], true, ly);
+    const T* face_y = a.tab + (size_t)(1 * 2) * 6 * kMaxLayers;
+    const T* face_z = a.tab + (size_t)(2 * 2) * 6 * kMaxLayers;
+    const bool row_lt = j < Ny, row_in = j >= 1 && j < Ny;
+
+    size_t idx = ((size_t)t.klb * a.ny1 + j) * px + i0;
+    P ex = ldv<T, V>(Ex + idx), ey = ldv<T, V>(Ey + idx);
+
+    for (int kl = t.klb; kl < t.kle; ++kl, idx += sz) {
+        const int k = kl + a.zoff;
+        int lk;
+        const int zk = zone_h(k, Nz, a.np[2][0], a.np[2][1], true, lk);
+        const bool pl_lt = k < Nz, pl_in = k >= 1 && k < Nz;
+
+        P ex_kp = zero_pack<T, V>(), ey_kp = zero_pack<T, V>();
+        if (kl + 1 < a.nzp) { ex_kp = ldv<T, V>(Ex + idx + sz); ey_kp = ldv<T, V>(Ey + idx + sz); }
+        const P ez = ldv<T, V>(Ez + idx);
+        P ex_jp = zero_pack<T, V>(), ez_jp = zero_pack<T, V>();
+        if (row_lt) { ex_jp = ldv<T, V>(Ex + idx + px); ez_jp = ldv<T, V>(Ez + idx + px); }
+        const T ey_r = right_of<T, V>(ey, Ey + idx, i0, lane, px);
+        const T ez_r = right_of<T, V>(ez, Ez + idx, i0, lane, px);
+
+        const size_t row_n = ((size_t)kl * a.ny1 + j) * a.xwn + i0;
+        const size_t row_p = ((size_t)kl * a.ny1 + j) * a.xwp + (i0 - a.xp0);
+
+        // ---- Bx: +dEy/dz, then -dEz/dy; columns 1..Nx-1, rows 0..Ny-1, planes 0..Nz-1
+        if (row_lt && pl_lt) {
+            P b = ldv<T, V>(a.B[0] + idx);
+            apply_uniform<+1, T, V>(b, diff<T, V>(ey_kp, ey), t.m_in, zk, lk, face_z, 3, a.dtd[2], a.dt,
+                                    a.phM[0][2][0] + ((size_t)lk * a.ny1 + j) * px + i0,
+                                    a.phM[0][2][1] + ((size_t)lk * a.ny1 + j) * px + i0);
+            apply_uniform<-1, T, V>(b, diff<T, V>(ez_jp, ez), t.m_in, zy, ly, face_y, 3, a.dtd[1], a.dt,
+                                    a.phM[0][1][0] + ((size_t)kl * a.np[1][0] + ly) * px + i0,
+                                    a.phM[0][1][1] + ((size_t)kl * a.np[1][1] + ly) * px + i0);
+            stv<T, V>(a.B[0] + idx, b);
+            stv<T, V>(a.H[0] + idx, MU ? divide<T, V>(b, ldv<T, V>(a.mu[0] + idx)) : divide<T, V>(b, a.mu0));
+        }
+        // ---- By: +dEz/dx, then -dEx/dz; rows 1..Ny-1 (row 0 and Ny only take H = B/mu), planes 0..Nz-1
+        if (pl_lt) {
+            P b = ldv<T, V>(a.B[1] + idx);
+            apply_x<+1, true, true, T, V>(b, diff_fwd_x<T, V>(ez, ez_r), row_in ? t.m_lt : 0u, i0, Nx, a.np[0][0], a.np[0][1], a.xrow, px,
+                                    a.dtd[0], a.dt, t.lane_n ? a.phM[1][0][0] + row_n : nullptr, t.lane_p ? a.phM[1][0][1] + row_p : nullptr);
+            apply_uniform<-1, T, V>(b, diff<T, V>(ex_kp, ex), row_in ? t.m_lt : 0u, zk, lk, face_z, 3, a.dtd[2], a.dt,
+                                    a.phM[1][2][0] + ((size_t)lk * a.ny1 + j) * px + i0,
+                                    a.phM[1][2][1] + ((size_t)lk * a.ny1 + j) * px + i0);
+            stv<T, V>(a.B[1] + idx, b);
+            stv<T, V>(a.H[1] + idx, MU ? divide<T, V>(b, ldv<T, V>(a.mu[1] + idx)) : divide<T, V>(b, a.mu0));
+        }
+        // ---- Bz: +dEx/dy, then -dEy/dx; rows 0..Ny-1, planes 1..Nz-1 (planes 0 and Nz only take H = B/mu)
+        if (row_lt) {
+            P b = ldv<T, V>(a.B[2] + idx);
+            apply_uniform<+1, T, V>(b, diff<T, V>(ex_jp, ex), pl_in ? t.m_lt : 0u, zy, ly, face_y, 3, a.dtd[1], a.dt,
+                                    a.phM[2][1][0] + ((size_t)kl * a.np[1][0] + ly) * px + i0,
+                                    a.phM[2][1][1] + ((size_t)kl * a.np[1][1] + ly) * px + i0);
+            apply_x<-1, true, true, T, V>(b, diff_fwd_x<T, V>(ey, ey_r), pl_in ? t.m_lt : 0u, i0, Nx, a.np[0][0], a.np[0][1], a.xrow, px,
+                                    a.dtd[0], a.dt, t.lane_n ? a.phM[2][0][0] + row_n : nullptr, t.lane_p ? a.phM[2][0][1] + row_p : nullptr);
+            stv<T, V>(a.B[2] + idx, b);
+            stv<T, V>(a.H[2] + idx, MU ? divide<T, V>(b, ldv<T, V>(a.mu[2] + idx)) : divide<T, V>(b, a.mu0));
+        }
+        ex = ex_kp; ey = ey_kp;
+    }
+}
+
+}  // namespace fdtd

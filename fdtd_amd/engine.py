@@ -1,0 +1,189 @@
+"""ctypes binding of the engine's C ABI (include/fdtd_engine.h).
+
+Mirrors the reference's solver interface for the hot path: an ``Engine3D`` stands where
+``FDTD3D``'s private state plus ``updateE``/``updateH`` stood (fdtd3d/include/FDTD3D.h:17-195),
+an ``Engine2D`` where ``FDTD2D``'s state plus ``stepOnce`` stood (fdtd2d/include/FDTD2D.h:16-89).
+Arrays cross as float64 numpy arrays in the reference's own flat order.  There is no CPU
+fallback: without the built library (``fdtd_amd/libfdtd_engine.so``) or without a HIP device
+every constructor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfdtd_engine.so")
+
+# array ids (include/fdtd_engine.h)
+DX, DY, DZ, EX, EY, EZ, BX, BY, BZ, HX, HY, HZ = range(12)
+EPS_X, EPS_Y, EPS_Z, MU_X, MU_Y, MU_Z = range(12, 18)
+PHI_E, PHI_M, TAB, JX_MAG, JX_WF = 100, 200, 300, 400, 401
+MODE_FULL, MODE_LEAN = 0, 1
+PART_ALL, PART_EDGE, PART_INTERIOR = 0, 1, 2
+HALO_SEND_UP, HALO_RECV_LO, HALO_SEND_DOWN, HALO_RECV_HI = 0, 1, 2, 3
+
+D2_DY, D2_EY, D2_EY_N1, D2_EY_N2, D2_SEY, D2_SEY_N1, D2_SEY_N2 = range(7)
+D2_BX, D2_HX = 7, 8
+D2_BZ, D2_HZ = 14, 15
+D2_C1, D2_C2, D2_C3 = 21, 22, 23
+D2_PHI, D2_TAB, D2_JY = 100, 300, 400
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Desc3D(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("Nx", C.c_int32), ("Ny", C.c_int32), ("Nz", C.c_int32),
+                ("n_pml", C.c_int32 * 6), ("k_Jx", C.c_int32), ("n_wf", C.c_int32), ("precision", C.c_int32),
+                ("has_mu", C.c_int32), ("mode", C.c_int32), ("z_lo", C.c_int32), ("z_hi", C.c_int32),
+                ("device", C.c_int32), ("dx", C.c_double), ("dy", C.c_double), ("dz", C.c_double),
+                ("dt", C.c_double), ("mu0", C.c_double)]
+
+
+class Desc2D(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("Nx", C.c_int32), ("Nz", C.c_int32), ("n_pml", C.c_int32 * 4),
+                ("i_Jy", C.c_int32), ("k_Jy", C.c_int32), ("n_wf", C.c_int32), ("precision", C.c_int32),
+                ("device", C.c_int32), ("dx", C.c_double), ("dz", C.c_double), ("dt", C.c_double),
+                ("mu0", C.c_double), ("eps0", C.c_double)]
+
+
+_lib = None
+_dp = C.POINTER(C.c_double)
+
+
+def lib() -> C.CDLL:
+    """Load the shared library; raise if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); there is no fallback path")
+        L = C.CDLL(LIB_PATH)
+        L.fdtd_last_error.restype = C.c_char_p
+        L.fdtd_engine_version.restype = C.c_char_p
+        for name in ("fdtd3d_array_size", "fdtd3d_device_bytes", "fdtd2d_array_size", "fdtd2d_device_bytes"):
+            getattr(L, name).restype = C.c_size_t
+        _lib = L
+    return _lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise EngineError(f"{what}: {lib().fdtd_last_error().decode()} (status {rc})")
+
+
+def _stream_handle(stream) -> C.c_void_p:
+    if stream is None:
+        return C.c_void_p(0)
+    if hasattr(stream, "cuda_stream"):       # torch.cuda.Stream
+        return C.c_void_p(stream.cuda_stream)
+    return C.c_void_p(int(stream))
+
+
+class _Common:
+    _p = ""
+
+    def _fn(self, name):
+        return getattr(lib(), self._p + name)
+
+    def size(self, id_: int) -> int:
+        return self._fn("array_size")(self.h, C.c_int(id_))
+
+    def set(self, id_: int, arr) -> None:
+        a = np.ascontiguousarray(arr, dtype=np.float64).ravel()
+        _check(self._fn("set_array")(self.h, C.c_int(id_), a.ctypes.data_as(_dp), C.c_size_t(a.size)), f"set_array({id_})")
+
+    def get(self, id_: int, shape=None, out=None) -> np.ndarray:
+        n = self.size(id_)
+        if out is None:
+            out = np.zeros(n, dtype=np.float64)
+        flat = out.reshape(-1)
+        _check(self._fn("get_array")(self.h, C.c_int(id_), flat.ctypes.data_as(_dp), C.c_size_t(flat.size)), f"get_array({id_})")
+        return out.reshape(shape) if shape is not None else out
+
+    def sumsq(self, id_: int, stream=None) -> float:
+        v = C.c_double(0)
+        _check(self._fn("sumsq")(self.h, C.c_int(id_), C.byref(v), _stream_handle(stream)), f"sumsq({id_})")
+        return v.value
+
+    def device_bytes(self) -> int:
+        return self._fn("device_bytes")(self.h)
+
+    def kernel_timing(self, enable: bool) -> None:
+        _check(self._fn("kernel_timing")(self.h, C.c_int(int(enable))), "kernel_timing")
+
+    def kernel_time(self, kind: int):
+        """(launches, total device milliseconds) of kernel kind 0 (E) or 1 (H) since the last call."""
+        n, ms = C.c_int(0), C.c_double(0)
+        _check(self._fn("kernel_time")(self.h, C.c_int(kind), C.byref(n), C.byref(ms)), "kernel_time")
+        return n.value, ms.value
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self._fn("destroy")(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine3D(_Common):
+    """Device-resident 3-D Yee state of one z-slab plus its two half-step kernels."""
+    _p = "fdtd3d_"
+
+    def __init__(self, N, npml, d, dt, mu0, k_Jx, n_wf, precision=32, has_mu=False, mode=MODE_FULL,
+                 z_range=None, device=-1):
+        self.N, self.npml, self.precision = tuple(N), tuple(npml), precision
+        z_lo, z_hi = z_range if z_range is not None else (0, N[2])
+        desc = Desc3D(C.sizeof(Desc3D), N[0], N[1], N[2], (C.c_int32 * 6)(*npml), k_Jx, n_wf, precision, int(has_mu),
+                      mode, z_lo, z_hi, device, d[0], d[1], d[2], dt, mu0)
+        self.desc = desc
+        self.h = C.c_void_p()
+        _check(lib().fdtd3d_create(C.byref(desc), C.byref(self.h)), "fdtd3d_create")
+
+    def step(self, n0: int, count: int = 1, stream=None) -> None:
+        _check(lib().fdtd3d_step(self.h, C.c_int(n0), C.c_int(count), _stream_handle(stream)), "fdtd3d_step")
+
+    def half_e(self, n: int, part: int = PART_ALL, stream=None) -> None:
+        _check(lib().fdtd3d_half_e(self.h, C.c_int(n), C.c_int(part), _stream_handle(stream)), "fdtd3d_half_e")
+
+    def half_h(self, part: int = PART_ALL, stream=None) -> None:
+        _check(lib().fdtd3d_half_h(self.h, C.c_int(part), _stream_handle(stream)), "fdtd3d_half_h")
+
+    def fill_materials(self, seed, eps_lo, eps_hi, mu_lo, mu_hi) -> None:
+        _check(lib().fdtd3d_fill_materials(self.h, C.c_uint64(seed), C.c_double(eps_lo), C.c_double(eps_hi),
+                                           C.c_double(mu_lo), C.c_double(mu_hi)), "fdtd3d_fill_materials")
+
+    def halo(self, which: int, comp: int):
+        """(device pointer, bytes) of one ghost-exchange plane."""
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(lib().fdtd3d_halo(self.h, C.c_int(which), C.c_int(comp), C.byref(p), C.byref(n)), "fdtd3d_halo")
+        return p.value, n.value
+
+    def checksum(self, id_: int, stream=None) -> int:
+        v = C.c_uint64(0)
+        _check(lib().fdtd3d_checksum(self.h, C.c_int(id_), C.byref(v), _stream_handle(stream)), f"checksum({id_})")
+        return v.value
+
+
+class Engine2D(_Common):
+    """Device-resident 2-D (Ey, Hx, Hz) state with Lorentz histories plus its two kernels."""
+    _p = "fdtd2d_"
+
+    def __init__(self, Nx, Nz, npml, dx, dz, dt, mu0, eps0, i_Jy, k_Jy, n_wf, precision=32, device=-1):
+        self.Nx, self.Nz, self.npml, self.precision = Nx, Nz, tuple(npml), precision
+        desc = Desc2D(C.sizeof(Desc2D), Nx, Nz, (C.c_int32 * 4)(*npml), i_Jy, k_Jy, n_wf, precision, device,
+                      dx, dz, dt, mu0, eps0)
+        self.desc = desc
+        self.h = C.c_void_p()
+        _check(lib().fdtd2d_create(C.byref(desc), C.byref(self.h)), "fdtd2d_create")
+
+    def step(self, n0: int, count: int = 1, stream=None) -> None:
+        _check(lib().fdtd2d_step(self.h, C.c_int(n0), C.c_int(count), _stream_handle(stream)), "fdtd2d_step")

@@ -135,6 +135,11 @@ int fdtd3d_halo(fdtd3d_handle h, int which, int comp, void** dev_ptr, size_t* by
  * (diagnostic / checksum). */
 int fdtd3d_sumsq(fdtd3d_handle h, int id, double* out, void* stream);
 
+/* Order-independent 64-bit checksum over owned cells of array `id` (value bits mixed with the
+ * canonical cell index, summed modulo 2^64; zeros of either sign contribute nothing), for
+ * bit-exact comparisons at sizes too large to download. */
+int fdtd3d_checksum(fdtd3d_handle h, int id, uint64_t* out, void* stream);
+
 /* Bytes of device memory held by the handle. */
 size_t fdtd3d_device_bytes(fdtd3d_handle h);
 
