@@ -41,6 +41,11 @@ __global__ void k_fill_hash(T* arr, CompGeom g, uint64_t seed, uint32_t stream, 
     }
 }
 
+template <typename T>
+__global__ void k_fill_const(T* arr, size_t n, T v) {
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) arr[t] = v;
+}
+
 template <typename T> struct BitsOf;
 template <> struct BitsOf<float> { __host__ __device__ static uint64_t get(float v) { if (v == 0.0f) v = 0.0f; union { float f; uint32_t u; } x; x.f = v; return x.u; } };
 template <> struct BitsOf<double> { __host__ __device__ static uint64_t get(double v) { if (v == 0.0) v = 0.0; union { double f; uint64_t u; } x; x.f = v; return x.u; } };
@@ -178,11 +183,8 @@ struct Engine3 : fdtd3d_engine {
     }
 
     int fill_const(T* p, size_t n, T v) {
-        std::vector<T> h(std::min<size_t>(n, (size_t)1 << 22), v);
-        for (size_t o = 0; o < n; o += h.size()) {
-            const size_t m = std::min(h.size(), n - o);
-            FDTD_HIP(hipMemcpy(p + o, h.data(), m * sizeof(T), hipMemcpyHostToDevice));
-        }
+        hipLaunchKernelGGL(k_fill_const<T>, dim3(2048), dim3(256), 0, 0, p, n, v);
+        FDTD_HIP(hipGetLastError());
         return FDTD_OK;
     }
 

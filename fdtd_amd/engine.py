@@ -187,3 +187,20 @@ class Engine2D(_Common):
 
     def step(self, n0: int, count: int = 1, stream=None) -> None:
         _check(lib().fdtd2d_step(self.h, C.c_int(n0), C.c_int(count), _stream_handle(stream)), "fdtd2d_step")
+
+
+class _DeviceSpan:
+    """Exposes a raw device address range through __cuda_array_interface__ so that torch can wrap it
+    without copying (torch is only plumbing here: device tensors for torch.distributed)."""
+
+    def __init__(self, ptr: int, nbytes: int, itemsize: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes // itemsize,), "typestr": "<f4" if itemsize == 4 else "<f8",
+                                         "data": (ptr, False), "version": 2}
+
+
+def halo_tensor(engine: "Engine3D", which: int, comp: int):
+    """torch tensor aliasing one ghost-exchange plane of the engine (no copy)."""
+    import torch
+    ptr, nbytes = engine.halo(which, comp)
+    itemsize = 4 if engine.precision == 32 else 8
+    return torch.as_tensor(_DeviceSpan(ptr, nbytes, itemsize), device=torch.device("cuda", torch.cuda.current_device()))

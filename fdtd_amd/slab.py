@@ -1,0 +1,110 @@
+"""z-slab decomposition of the 3-D grid over the GPUs of one node, one process per GPU.
+
+Rank r owns the cell layers [z_lo, z_hi) of every component (the last rank also the closing wall
+plane k = Nz).  Two nearest-neighbour exchanges per step, each one x-y plane of two tangential
+components:
+
+  after the H-half: Hx, Hy of the top owned layer go up   (the D update at the next slab's first
+                    layer needs H(k) - H(k-1), reference sweeps FDTD3D.cpp:545, :627)
+  after the E-half: Ex, Ey of the lowest owned layer go down (the B update at this slab's top layer
+                    needs E(k+1) - E(k), FDTD3D.cpp:799, :912)
+
+With x unit-stride and z slowest each message is one contiguous device range, sent straight out of
+and received straight into the engine's arrays with torch.distributed (RCCL over xGMI on the GPU
+box, gloo in the CPU tests).  Each exchange is started right after the single-plane "edge" kernel
+that produces the data and overlaps the next half step's interior kernel, which does not touch the
+ghost plane; the wait sits in front of the one edge kernel that needs it.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+PART_ALL, PART_EDGE, PART_INTERIOR = 0, 1, 2
+
+
+def partition(Nz: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous, balanced layer ranges; every rank gets at least one layer."""
+    if world < 1 or Nz < world:
+        raise ValueError(f"cannot split {Nz} layers over {world} ranks")
+    base, extra = divmod(Nz, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+class HaloExchange:
+    """Posts the up / down plane exchanges of one rank and hands back the requests."""
+
+    def __init__(self, rank: int, world: int, send_up: Sequence, recv_lo: Sequence, send_down: Sequence, recv_hi: Sequence, group=None):
+        self.rank, self.world, self.group = rank, world, group
+        self.send_up, self.recv_lo, self.send_down, self.recv_hi = list(send_up), list(recv_lo), list(send_down), list(recv_hi)
+
+    def _post(self, ops):
+        import torch.distributed as dist
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def start_up(self):
+        """Top owned H planes -> rank+1's low ghost; own low ghost <- rank-1."""
+        import torch.distributed as dist
+        ops = []
+        if self.rank + 1 < self.world:
+            ops += [dist.P2POp(dist.isend, t, self.rank + 1, self.group) for t in self.send_up]
+        if self.rank > 0:
+            ops += [dist.P2POp(dist.irecv, t, self.rank - 1, self.group) for t in self.recv_lo]
+        return self._post(ops)
+
+    def start_down(self):
+        """Lowest owned E planes -> rank-1's high ghost; own high ghost <- rank+1."""
+        import torch.distributed as dist
+        ops = []
+        if self.rank > 0:
+            ops += [dist.P2POp(dist.isend, t, self.rank - 1, self.group) for t in self.send_down]
+        if self.rank + 1 < self.world:
+            ops += [dist.P2POp(dist.irecv, t, self.rank + 1, self.group) for t in self.recv_hi]
+        return self._post(ops)
+
+    @staticmethod
+    def wait(reqs) -> None:
+        for r in reqs:
+            r.wait()
+
+
+class SlabStepper:
+    """One rank's time loop.  `engine` needs half_e(n, part), half_h(part); `exchange` a HaloExchange."""
+
+    def __init__(self, engine, exchange: HaloExchange, stream=None):
+        self.engine, self.x, self.stream = engine, exchange, stream
+        self._pending_h: list = []       # H planes travelling up since the previous step
+
+    def step(self, n: int) -> None:
+        e, s = self.engine, self.stream
+        # E-half: layers above the lowest one never look at the low ghost
+        e.half_e(n, PART_INTERIOR, s)
+        HaloExchange.wait(self._pending_h)
+        e.half_e(n, PART_EDGE, s)
+        pending_e = self.x.start_down()
+        # H-half: layers below the top one never look at the high ghost
+        e.half_h(PART_INTERIOR, s)
+        HaloExchange.wait(pending_e)
+        e.half_h(PART_EDGE, s)
+        self._pending_h = self.x.start_up()
+
+    def run(self, n0: int, count: int) -> None:
+        for n in range(n0, n0 + count):
+            self.step(n)
+
+    def finish(self) -> None:
+        """Complete the exchange left in flight by the last step."""
+        HaloExchange.wait(self._pending_h)
+        self._pending_h = []
+
+
+def make_gpu_stepper(engine, rank: int, world: int, group=None, stream=None) -> SlabStepper:
+    """Wire an Engine3D's own ghost planes into a SlabStepper (tensors alias engine memory)."""
+    from .engine import HALO_RECV_HI, HALO_RECV_LO, HALO_SEND_DOWN, HALO_SEND_UP, halo_tensor
+    planes = {w: [halo_tensor(engine, w, c) for c in (0, 1)] for w in (HALO_SEND_UP, HALO_RECV_LO, HALO_SEND_DOWN, HALO_RECV_HI)}
+    x = HaloExchange(rank, world, planes[HALO_SEND_UP], planes[HALO_RECV_LO], planes[HALO_SEND_DOWN], planes[HALO_RECV_HI], group)
+    return SlabStepper(engine, x, stream)
