@@ -53,7 +53,7 @@ struct Engine2 : fdtd2d_engine {
     T* tab_d = nullptr; T* xrow_d = nullptr; double* red_d = nullptr;
     std::vector<double> tab_h;
     std::vector<T> Jy;
-    int chunk = 32;
+    int chunk = 32, remap = 1;
     std::vector<void*> allocs;
 
     ~Engine2() override { for (void* p : allocs) (void)hipFree(p); timer.release(); }
@@ -76,6 +76,7 @@ struct Engine2 : fdtd2d_engine {
         xp0 = (d.Nx - np[0][1]) / 4 * 4;
         xwp = np[0][1] > 0 ? round_up(d.Nx - xp0, 4) : 0;
         if (const char* e = getenv("FDTD_Z_CHUNK2D")) { int c = atoi(e); if (c >= 1 && c <= 65536) chunk = c; }
+        if (const char* e = getenv("FDTD_XCD_REMAP")) remap = atoi(e) != 0;
         int rc;
         const size_t fb = (fsize + px) * sizeof(T);
         if ((rc = dalloc((void**)&Dy, fb)) || (rc = dalloc((void**)&Bx, fb)) || (rc = dalloc((void**)&Bz, fb))) return rc;
@@ -219,6 +220,7 @@ struct Engine2 : fdtd2d_engine {
         a.iJ = d.i_Jy; a.kJ = d.k_Jy; a.src_on = 0; a.jy = (T)0;
         a.dt = (T)d.dt; a.dtd[0] = (T)(d.dt / d.dx); a.dtd[1] = (T)(d.dt / d.dz); a.mu0 = (T)d.mu0; a.eps0 = (T)d.eps0;
         a.chunk = chunk;
+        a.remap = remap;
         a.ntx = px / (kLanes * V);
         a.nbx = (a.ntx + kWavesPerBlock - 1) / kWavesPerBlock;
         a.nbz = (nz1 + chunk - 1) / chunk;

@@ -93,6 +93,7 @@ struct fdtd3d_engine {
     virtual int halo(int which, int comp, void** p, size_t* bytes) = 0;
     virtual int reduce(int id, double* sumsq, uint64_t* checksum, hipStream_t s) = 0;
     virtual size_t device_bytes() = 0;
+    virtual int tune(int chunk, int remap) = 0;
     fdtd3d_desc d;
     KernelTimer timer;
 };
@@ -117,7 +118,7 @@ struct Engine3 : fdtd3d_engine {
     double* red_d = nullptr;          // reduction scratch: 1024 partial sums + checksum word
     std::vector<double> tab_h;        // [3][2][6][kMaxLayers], fp64 master copy
     std::vector<T> wf;
-    int chunk = 16;
+    int chunk = 8, remap = 1;
     std::vector<void*> allocs;
 
     ~Engine3() override {
@@ -150,6 +151,7 @@ struct Engine3 : fdtd3d_engine {
         xp0 = (d.Nx - np[0][1]) / 4 * 4;
         xwp = np[0][1] > 0 ? round_up(d.Nx - xp0, 4) : 0;
         if (const char* e = getenv("FDTD_Z_CHUNK")) { int c = atoi(e); if (c >= 1 && c <= 4096) chunk = c; }
+        if (const char* e = getenv("FDTD_XCD_REMAP")) remap = atoi(e) != 0;
 
         int rc;
         for (int f = 0; f < 6; ++f) for (int c = 0; c < 3; ++c) {
@@ -179,7 +181,7 @@ struct Engine3 : fdtd3d_engine {
         if ((rc = dalloc((void**)&mag_d, plane * sizeof(T)))) return rc;
         if ((rc = dalloc((void**)&red_d, 1025 * sizeof(double)))) return rc;
         wf.assign(d.n_wf > 0 ? d.n_wf : 0, (T)0);
-        return FDTD_OK;
+        return upload_tables();
     }
 
     int fill_const(T* p, size_t n, T v) {
@@ -189,6 +191,11 @@ struct Engine3 : fdtd3d_engine {
     }
 
     size_t device_bytes() override { return bytes; }
+    int tune(int c, int r) override {
+        if (c >= 1 && c <= 4096) chunk = c;
+        if (r == 0 || r == 1) remap = r;
+        return FDTD_OK;
+    }
 
     // ---- canonical <-> device index maps ------------------------------------------------
     struct Map {
@@ -239,19 +246,19 @@ struct Engine3 : fdtd3d_engine {
         auto own_k = [&](int k) { return (k >= d.z_lo && k < d.z_hi) || (last_rank && k == d.Nz); };
         switch (m.kind) {
             case 0: {
-                if (p0 >= d.Nx) return -1;
+                if (p0 >= d.Nx) return -2;
                 const int kl = p2 - zoff;
                 if (kl < 0 || kl >= nzp) return -1;
                 owned = own_k(p2);
                 return ((long long)kl * ny1 + p1) * px + p0;
             }
             case 1: {       // z face: canonical (i, j, l), device [l][j][i]
-                if (p0 >= d.Nx) return -1;
+                if (p0 >= d.Nx) return -2;
                 owned = own_k(layer_cell(m.mag, 2, m.s, p2));
                 return ((long long)p2 * ny1 + p1) * px + p0;
             }
             case 2: {       // y face: canonical (i, l, k), device [kl][l][i]
-                if (p0 >= d.Nx) return -1;
+                if (p0 >= d.Nx) return -2;
                 const int kl = p2 - zoff;
                 if (kl < 0 || kl >= nzp) return -1;
                 owned = own_k(p2);
@@ -261,7 +268,7 @@ struct Engine3 : fdtd3d_engine {
                 const int kl = p2 - zoff;
                 if (kl < 0 || kl >= nzp) return -1;
                 const int col = layer_cell(m.mag, 0, m.s, p0);
-                if (col < 0 || col >= d.Nx) return -1;
+                if (col < 0 || col >= d.Nx) return -2;
                 owned = own_k(p2);
                 return m.s ? ((long long)kl * ny1 + p1) * xwp + (col - xp0) : ((long long)kl * ny1 + p1) * xwn + col;
             }
@@ -282,16 +289,20 @@ struct Engine3 : fdtd3d_engine {
         std::vector<T> t(tab_h.size());
         for (size_t q = 0; q < t.size(); ++q) t[q] = (T)tab_h[q];
         FDTD_HIP(hipMemcpy(tab_d, t.data(), t.size() * sizeof(T), hipMemcpyHostToDevice));
-        // x-face rows expanded per column: kinds 0-2 for the backward-difference (D) zones,
-        // 3-5 for the forward-difference (B) zones
+        // x-axis coefficient rows, one entry per column: CPML columns carry the tabulated (b, a, C),
+        // plain columns (0, 0, dt/dx), columns the reference's sweeps skip (0, 0, 0).  Kinds 0-2 for
+        // the backward-difference (D) terms, 3-5 for the forward-difference (B) terms.
         std::vector<T> xr((size_t)6 * px, (T)0);
         auto tb = [&](int s, int kind, int l) { return (T)tab_h[((size_t)(0 * 2 + s) * 6 + kind) * kMaxLayers + l]; };
+        const T cmid = (T)(d.dt / d.dx);
         for (int i = 0; i < d.Nx; ++i) {
             int l;
             int z = zone_e(i, d.Nx, np[0][0], np[0][1], l);
             if (z == Z_NEG || z == Z_POS) for (int q = 0; q < 3; ++q) xr[(size_t)q * px + i] = tb(z == Z_POS, q, l);
+            else if (z == Z_MID) xr[(size_t)2 * px + i] = cmid;
             z = zone_h(i, d.Nx, np[0][0], np[0][1], true, l);
             if (z == Z_NEG || z == Z_POS) for (int q = 3; q < 6; ++q) xr[(size_t)q * px + i] = tb(z == Z_POS, q, l);
+            else if (z == Z_MID) xr[(size_t)5 * px + i] = cmid;
         }
         FDTD_HIP(hipMemcpy(xrow_d, xr.data(), xr.size() * sizeof(T), hipMemcpyHostToDevice));
         return FDTD_OK;
@@ -331,16 +342,31 @@ struct Engine3 : fdtd3d_engine {
         Map m;
         if (!make_map(id, m)) return fail(FDTD_ERR_ARG, "get_array: unknown array id %d", id);
         if (n == 0) return FDTD_OK;
-        if (!m.dev) return fail(FDTD_ERR_STATE, "get_array(%d): array is not resident in this storage mode", id);
         FDTD_HIP(hipDeviceSynchronize());
         std::vector<T> st(m.dev_elems);
-        FDTD_HIP(hipMemcpy(st.data(), m.dev, st.size() * sizeof(T), hipMemcpyDeviceToHost));
+        const bool derived = !full && m.kind == 0 && (id / 3 == 1 || id / 3 == 3);
+        if (derived) {
+            // lean storage: E = D/eps and H = B/mu are formed here with the division the kernels use
+            const int c = id % 3, num = id / 3 == 1 ? c : 6 + c, den = id / 3 == 1 ? 12 + c : 15 + c;
+            FDTD_HIP(hipMemcpy(st.data(), fld[num], st.size() * sizeof(T), hipMemcpyDeviceToHost));
+            if (fld[den]) {
+                std::vector<T> dn(m.dev_elems);
+                FDTD_HIP(hipMemcpy(dn.data(), fld[den], dn.size() * sizeof(T), hipMemcpyDeviceToHost));
+                for (size_t q = 0; q < st.size(); ++q) st[q] = st[q] / dn[q];
+            } else {
+                const T m0 = (T)d.mu0;
+                for (size_t q = 0; q < st.size(); ++q) st[q] = st[q] / m0;
+            }
+        } else {
+            if (!m.dev) return fail(FDTD_ERR_STATE, "get_array(%d): array is not resident in this storage mode", id);
+            FDTD_HIP(hipMemcpy(st.data(), m.dev, st.size() * sizeof(T), hipMemcpyDeviceToHost));
+        }
         size_t o = 0;
         for (int p0 = 0; p0 < m.n[0]; ++p0) for (int p1 = 0; p1 < m.n[1]; ++p1) for (int p2 = 0; p2 < m.n[2]; ++p2, ++o) {
             bool owned;
             const long long off = dev_off(m, p0, p1, p2, owned);
             if (off >= 0) { if (owned) host[o] = (double)st[(size_t)off]; }
-            else if (m.kind == 0 && p0 >= d.Nx) host[o] = 0.0;          // unstored wall column
+            else if (off == -2) host[o] = 0.0;                          // unstored wall column
         }
         return FDTD_OK;
     }
@@ -396,6 +422,7 @@ struct Engine3 : fdtd3d_engine {
         a.dt = (T)d.dt; a.dtd[0] = (T)(d.dt / d.dx); a.dtd[1] = (T)(d.dt / d.dy); a.dtd[2] = (T)(d.dt / d.dz); a.mu0 = (T)d.mu0;
         a.nbx = px / (kLanes * V); a.nby = (ny1 + kWavesPerBlock - 1) / kWavesPerBlock;
         a.chunk = chunk;
+        a.remap = remap;
         return a;
     }
     // planes [kl0,kl1) of a part; E-half edge = lowest owned plane, H-half edge = highest owned
@@ -424,25 +451,33 @@ struct Engine3 : fdtd3d_engine {
         FDTD_HIP(hipGetLastError());
         return FDTD_OK;
     }
+    int launch_e(const K3<T>& a, int kl0, int kl1, hipStream_t s) {
+        if (full) return d.has_mu ? launch(k3_half_e<T, true, false>, a, kl0, kl1, 0, s) : launch(k3_half_e<T, false, false>, a, kl0, kl1, 0, s);
+        return d.has_mu ? launch(k3_half_e<T, true, true>, a, kl0, kl1, 0, s) : launch(k3_half_e<T, false, true>, a, kl0, kl1, 0, s);
+    }
+    int launch_h(const K3<T>& a, int kl0, int kl1, hipStream_t s) {
+        if (full) return d.has_mu ? launch(k3_half_h<T, true, false>, a, kl0, kl1, 1, s) : launch(k3_half_h<T, false, false>, a, kl0, kl1, 1, s);
+        return d.has_mu ? launch(k3_half_h<T, true, true>, a, kl0, kl1, 1, s) : launch(k3_half_h<T, false, true>, a, kl0, kl1, 1, s);
+    }
     int half_e(int n, int part, hipStream_t s) override {
         K3<T> a = args();
         a.src_on = (n >= 0 && n < (int)wf.size()) ? 1 : 0;
         a.jx = a.src_on ? a.dt * wf[n] : (T)0;      // product formed first, as FDTD3D.cpp:482
         int kl0, kl1;
         if (!part_range(true, part, kl0, kl1)) return fail(FDTD_ERR_ARG, "half_e: bad part %d", part);
-        return launch(k3_half_e<T>, a, kl0, kl1, 0, s);
+        return launch_e(a, kl0, kl1, s);
     }
     int half_h(int part, hipStream_t s) override {
         K3<T> a = args();
         int kl0, kl1;
         if (part == FDTD3D_PART_INTERIOR) {
             // everything except the highest owned cell layer: the planes below it, and the closing plane above it
-            int rc = d.has_mu ? launch(k3_half_h<T, true>, a, 1, nzl, 1, s) : launch(k3_half_h<T, false>, a, 1, nzl, 1, s);
+            int rc = launch_h(a, 1, nzl, s);
             if (rc || !last_rank) return rc;
-            return d.has_mu ? launch(k3_half_h<T, true>, a, nzl + 1, nzp, 1, s) : launch(k3_half_h<T, false>, a, nzl + 1, nzp, 1, s);
+            return launch_h(a, nzl + 1, nzp, s);
         }
         if (!part_range(false, part, kl0, kl1)) return fail(FDTD_ERR_ARG, "half_h: bad part %d", part);
-        return d.has_mu ? launch(k3_half_h<T, true>, a, kl0, kl1, 1, s) : launch(k3_half_h<T, false>, a, kl0, kl1, 1, s);
+        return launch_h(a, kl0, kl1, s);
     }
 
     int halo(int which, int comp, void** p, size_t* nbytes) override {
@@ -474,6 +509,8 @@ int check_desc(const fdtd3d_desc* d) {
         // the reference's low, middle and high sweeps only tile the axis without overlap under this condition
         if (nn + np >= N[a]) return fail(FDTD_ERR_ARG, "CPML layers (%d+%d) do not fit %d cells along axis %d", nn, np, N[a], a);
     }
+    if (d->n_pml[0] > 0 && d->n_pml[1] > 0 && (d->Nx - d->n_pml[1]) / 4 * 4 < round_up(d->n_pml[0] + 1, 4))
+        return fail(FDTD_ERR_ARG, "x extent %d too small for separate low/high CPML strips of %d and %d layers", d->Nx, d->n_pml[0], d->n_pml[1]);
     if (d->z_lo < 0 || d->z_hi > d->Nz || d->z_lo >= d->z_hi) return fail(FDTD_ERR_ARG, "bad slab [%d,%d) of %d layers", d->z_lo, d->z_hi, d->Nz);
     if (d->k_Jx < 0 || d->k_Jx > d->Nz) return fail(FDTD_ERR_ARG, "source plane %d outside [0,%d]", d->k_Jx, d->Nz);
     if (d->mode != FDTD3D_MODE_FULL && d->mode != FDTD3D_MODE_LEAN) return fail(FDTD_ERR_ARG, "unknown storage mode %d", d->mode);
@@ -489,7 +526,6 @@ int fdtd3d_create(const fdtd3d_desc* desc, fdtd3d_handle* out) {
     if (!out) return fail(FDTD_ERR_ARG, "null output handle");
     *out = nullptr;
     if (int rc = check_desc(desc)) return rc;
-    if (desc->mode == FDTD3D_MODE_LEAN) return fail(FDTD_ERR_ARG, "lean storage mode is not available in this build");
     if (desc->device >= 0) FDTD_HIP(hipSetDevice(desc->device));
     int ndev = 0;
     FDTD_HIP(hipGetDeviceCount(&ndev));
@@ -531,6 +567,7 @@ int fdtd3d_halo(fdtd3d_handle h, int which, int comp, void** p, size_t* bytes) {
 int fdtd3d_sumsq(fdtd3d_handle h, int id, double* out, void* stream) { return h ? h->reduce(id, out, nullptr, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
 int fdtd3d_checksum(fdtd3d_handle h, int id, uint64_t* out, void* stream) { return h ? h->reduce(id, nullptr, out, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
 size_t fdtd3d_device_bytes(fdtd3d_handle h) { return h ? h->device_bytes() : 0; }
+int fdtd3d_tune(fdtd3d_handle h, int chunk, int remap) { return h ? h->tune(chunk, remap) : fail(FDTD_ERR_ARG, "null handle"); }
 int fdtd3d_kernel_timing(fdtd3d_handle h, int enable) {
     if (!h) return fail(FDTD_ERR_ARG, "null handle");
     h->timer.enabled = enable != 0;

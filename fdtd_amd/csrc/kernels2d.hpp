@@ -32,6 +32,7 @@ struct K2 {
     T jy;                          // dt * Jy[n]
     T dt, dtd[2], mu0, eps0;
     int chunk, nbx, nbz, ntx;      // rows per wave, workgroups along x and z, x tiles in total
+    int remap;
 };
 
 // Second-order Lorentz recursion of one sample (FDTD2D.cpp:369-373):
@@ -57,7 +58,7 @@ __device__ __forceinline__ Tile2<T> decode_tile2(const K2<T>& a) {
     Tile2<T> t;
     t.lane = threadIdx.x & (kLanes - 1);
     const int w = threadIdx.x >> 6;
-    const unsigned bid = xcd_contiguous(blockIdx.x, gridDim.x);
+    const unsigned bid = a.remap ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
     const int bx = bid % a.nbx, bz = bid / a.nbx;
     const int tx = bx * kWavesPerBlock + w;
     t.ok = tx < a.ntx;

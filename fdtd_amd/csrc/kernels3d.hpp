@@ -46,6 +46,7 @@ struct K3 {
     int kl0, kl1;      // planes to process [kl0, kl1)
     int chunk;         // planes per workgroup
     int nbx, nby, nbz;
+    int remap;         // 1: hand each XCD a contiguous range of tiles
 };
 
 template <typename T, int V>
@@ -171,20 +172,21 @@ __device__ __forceinline__ Pack<T, V> divide(const Pack<T, V>& n, T d) {
     return r;
 }
 
-template <typename T>
-struct Tile3 {
+// ---- loop-invariant per-lane state of the 3-D kernels ---------------------------------------
+template <typename T, int V>
+struct Lane3 {
     int lane, i0, j, klb, kle;
     bool ok;
-    unsigned m_lt, m_in;   // element masks: i < Nx ; 1 <= i < Nx
-    bool lane_n, lane_p;   // lane overlaps the low / high x auxiliary strip
+    bool first;                 // this lane's pack starts at the wall column i = 0
+    bool in_n, in_p;            // pack lies in the low / high x auxiliary strip
+    Pack<T, V> xb, xa, xC;      // x-axis coefficients of this lane's columns (see upload_tables)
 };
-template <typename T>
-__device__ __forceinline__ Tile3<T> decode_tile(const K3<T>& a) {
-    constexpr int V = VecWidth<T>::V;
-    Tile3<T> t;
+template <typename T, int V, bool HTYPE>
+__device__ __forceinline__ Lane3<T, V> decode_lane(const K3<T>& a) {
+    Lane3<T, V> t;
     t.lane = threadIdx.x & (kLanes - 1);
     const int w = threadIdx.x >> 6;
-    unsigned bid = xcd_contiguous(blockIdx.x, gridDim.x);
+    unsigned bid = a.remap ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
     const int bx = bid % a.nbx; bid /= a.nbx;
     const int by = bid % a.nby;
     const int bz = bid / a.nby;
@@ -193,30 +195,97 @@ __device__ __forceinline__ Tile3<T> decode_tile(const K3<T>& a) {
     t.klb = a.kl0 + bz * a.chunk;
     t.kle = min(t.klb + a.chunk, a.kl1);
     t.ok = t.j < a.ny1;
-    t.m_lt = 0; t.m_in = 0;
+    t.first = t.i0 == 0;
+    t.in_n = a.np[0][0] > 0 && t.i0 < a.xwn;
+    t.in_p = a.np[0][1] > 0 && t.i0 >= a.xp0 && t.i0 < a.xp0 + a.xwp;
+    const T* r = a.xrow + (HTYPE ? 3 : 0) * (size_t)a.px + t.i0;
+    t.xb = ldv<T, V>(r); t.xa = ldv<T, V>(r + a.px); t.xC = ldv<T, V>(r + 2 * (size_t)a.px);
+    return t;
+}
+
+// Term along y or z: one zone for the whole wave.  Padding columns (i >= Nx) hold zeros in every
+// input and so stay zero; `skip0` leaves the wall column i = 0 untouched for the terms whose sweeps
+// start at i = 1.  Same operation order per cell as apply_mid / apply_pml above.
+template <int SIGN, typename T, int V>
+__device__ __forceinline__ void term_u(Pack<T, V>& d, const Pack<T, V>& curl, bool skip0, int zone, int l,
+                                       const T* __restrict__ face, int kb, T cmid, T dt, T* phi_n, T* phi_p) {
+    if (zone == Z_NONE) return;
+    const T d0 = d.v[0];
+    if (zone == Z_MID) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) { const T v = cmid * curl.v[e]; d.v[e] = SIGN > 0 ? d.v[e] + v : d.v[e] - v; }
+    } else {
+        const T* t = face + (zone == Z_POS ? 6 * kMaxLayers : 0) + kb * kMaxLayers + l;
+        const T b = t[0], a = t[kMaxLayers], C = t[2 * kMaxLayers];
+        T* phi = zone == Z_POS ? phi_p : phi_n;
+        Pack<T, V> ph = ldv<T, V>(phi);
+        const T p0 = ph.v[0];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const T p = b * ph.v[e] + a * curl.v[e];
+            ph.v[e] = p;
+            const T v = C * curl.v[e] + dt * p;
+            d.v[e] = SIGN > 0 ? d.v[e] + v : d.v[e] - v;
+        }
+        if (skip0) ph.v[0] = p0;
+        stv<T, V>(phi, ph);
+    }
+    if (skip0) d.v[0] = d0;
+}
+// Term along x.  Every column carries its own coefficients (b, a, C): CPML columns the tabulated
+// ones, plain columns (0, 0, dt/dx), columns the sweep skips (0, 0, 0); with phi = 0 outside the
+// strips, C*curl + dt*(0*0 + 0*curl) is C*curl to the bit (the sign of a zero result aside).
+template <int SIGN, typename T, int V>
+__device__ __forceinline__ void term_x(Pack<T, V>& d, const Pack<T, V>& curl, const Lane3<T, V>& t, T dt, T* phi) {
+    Pack<T, V> ph = zero_pack<T, V>();
+    if (phi) ph = ldv<T, V>(phi);
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-        const int i = t.i0 + e;
-        if (i < a.Nx) t.m_lt |= 1u << e;
-        if (i >= 1 && i < a.Nx) t.m_in |= 1u << e;
+        const T p = t.xb.v[e] * ph.v[e] + t.xa.v[e] * curl.v[e];
+        ph.v[e] = p;
+        const T v = t.xC.v[e] * curl.v[e] + dt * p;
+        d.v[e] = SIGN > 0 ? d.v[e] + v : d.v[e] - v;
     }
-    t.lane_n = a.np[0][0] > 0 && t.i0 < a.xwn;
-    t.lane_p = a.np[0][1] > 0 && t.i0 >= a.xp0 && t.i0 < a.xp0 + a.xwp;
-    return t;
+    if (phi) stv<T, V>(phi, ph);
+}
+
+// ---- where the E-half finds H and the H-half finds E --------------------------------------
+// FULL storage: the arrays written by the previous half step.  LEAN storage: E and H are not
+// resident; the consumer recomputes them from D/eps and B/mu with the same division the producer
+// would have stored, so both modes yield identical bits.
+template <typename T, int V, bool MU, bool LEAN>
+__device__ __forceinline__ Pack<T, V> load_h(const K3<T>& a, int c, size_t idx) {
+    if (!LEAN) return ldv<T, V>(a.H[c] + idx);
+    const Pack<T, V> b = ldv<T, V>(a.B[c] + idx);
+    return MU ? divide<T, V>(b, ldv<T, V>(a.mu[c] + idx)) : divide<T, V>(b, a.mu0);
+}
+template <typename T, bool MU, bool LEAN>
+__device__ __forceinline__ T load_h1(const K3<T>& a, int c, size_t idx) {
+    if (!LEAN) return a.H[c][idx];
+    return MU ? a.B[c][idx] / a.mu[c][idx] : a.B[c][idx] / a.mu0;
+}
+template <typename T, int V, bool LEAN>
+__device__ __forceinline__ Pack<T, V> load_e(const K3<T>& a, int c, size_t idx) {
+    if (!LEAN) return ldv<T, V>(a.E[c] + idx);
+    return divide<T, V>(ldv<T, V>(a.D[c] + idx), ldv<T, V>(a.eps[c] + idx));
+}
+template <typename T, bool LEAN>
+__device__ __forceinline__ T load_e1(const K3<T>& a, int c, size_t idx) {
+    if (!LEAN) return a.E[c][idx];
+    return a.D[c][idx] / a.eps[c][idx];
 }
 
 // ------------------------------------------------------------------ E-half --
 // D += curl H (CPML folded in), Dx += dt*wf[n]*mag on the source plane, E = D/eps.
-template <typename T>
+template <typename T, bool MU, bool LEAN>
 __global__ void __launch_bounds__(256) k3_half_e(const K3<T> a) {
     constexpr int V = VecWidth<T>::V;
     using P = Pack<T, V>;
-    const Tile3<T> t = decode_tile(a);
+    const Lane3<T, V> t = decode_lane<T, V, false>(a);
     if (!t.ok) return;                       // whole wave leaves: one row per wave
     const int j = t.j, i0 = t.i0, lane = t.lane;
     const size_t sz = (size_t)a.ny1 * a.px;
-    const int Nx = a.Nx, Ny = a.Ny, Nz = a.Nz, px = a.px;
-    const T* __restrict__ Hx = a.H[0]; const T* __restrict__ Hy = a.H[1]; const T* __restrict__ Hz = a.H[2];
+    const int Ny = a.Ny, Nz = a.Nz, px = a.px;
 
     int ly;
     const int zy = zone_e(j, Ny, a.np[1][0], a.np[1][1], ly);
@@ -226,7 +295,7 @@ __global__ void __launch_bounds__(256) k3_half_e(const K3<T> a) {
 
     size_t idx = ((size_t)t.klb * a.ny1 + j) * px + i0;
     P hx_km = zero_pack<T, V>(), hy_km = zero_pack<T, V>();
-    if (t.klb + a.zoff >= 1) { hx_km = ldv<T, V>(Hx + idx - sz); hy_km = ldv<T, V>(Hy + idx - sz); }
+    if (t.klb + a.zoff >= 1) { hx_km = load_h<T, V, MU, LEAN>(a, 0, idx - sz); hy_km = load_h<T, V, MU, LEAN>(a, 1, idx - sz); }
 
     for (int kl = t.klb; kl < t.kle; ++kl, idx += sz) {
         const int k = kl + a.zoff;
@@ -234,53 +303,52 @@ __global__ void __launch_bounds__(256) k3_half_e(const K3<T> a) {
         const int zk = zone_e(k, Nz, a.np[2][0], a.np[2][1], lk);
         const bool pl_lt = k < Nz, pl_in = k >= 1 && k < Nz;
 
-        const P hx = ldv<T, V>(Hx + idx), hy = ldv<T, V>(Hy + idx), hz = ldv<T, V>(Hz + idx);
+        // every load of the plane is issued before the first use; all addresses are inside the
+        // padded boxes (components that do not exist at this row/plane read zeros)
+        const P hx = load_h<T, V, MU, LEAN>(a, 0, idx), hy = load_h<T, V, MU, LEAN>(a, 1, idx), hz = load_h<T, V, MU, LEAN>(a, 2, idx);
         P hx_jm = zero_pack<T, V>(), hz_jm = zero_pack<T, V>();
-        if (j >= 1) { hx_jm = ldv<T, V>(Hx + idx - px); hz_jm = ldv<T, V>(Hz + idx - px); }
-        const T hy_l = left_of<T, V>(hy, Hy + idx, i0, lane);
-        const T hz_l = left_of<T, V>(hz, Hz + idx, i0, lane);
+        if (j >= 1) { hx_jm = load_h<T, V, MU, LEAN>(a, 0, idx - px); hz_jm = load_h<T, V, MU, LEAN>(a, 2, idx - px); }
+        P dx = ldv<T, V>(a.D[0] + idx), dy = ldv<T, V>(a.D[1] + idx), dz = ldv<T, V>(a.D[2] + idx);
+        P ex = zero_pack<T, V>(), ey = ex, ez = ex;
+        if (!LEAN) { ex = ldv<T, V>(a.eps[0] + idx); ey = ldv<T, V>(a.eps[1] + idx); ez = ldv<T, V>(a.eps[2] + idx); }
 
-        const size_t row_n = ((size_t)kl * a.ny1 + j) * a.xwn + i0;
-        const size_t row_p = ((size_t)kl * a.ny1 + j) * a.xwp + (i0 - a.xp0);
+        T hy_l = __shfl_up(hy.v[V - 1], 1), hz_l = __shfl_up(hz.v[V - 1], 1);
+        if (lane == 0) {
+            hy_l = i0 > 0 ? load_h1<T, MU, LEAN>(a, 1, idx - 1) : (T)0;
+            hz_l = i0 > 0 ? load_h1<T, MU, LEAN>(a, 2, idx - 1) : (T)0;
+        }
+        T* phx = t.in_n ? a.phE[1][0][0] + ((size_t)kl * a.ny1 + j) * a.xwn + i0
+                        : (t.in_p ? a.phE[1][0][1] + ((size_t)kl * a.ny1 + j) * a.xwp + (i0 - a.xp0) : nullptr);
+        T* phx2 = t.in_n ? a.phE[2][0][0] + ((size_t)kl * a.ny1 + j) * a.xwn + i0
+                         : (t.in_p ? a.phE[2][0][1] + ((size_t)kl * a.ny1 + j) * a.xwp + (i0 - a.xp0) : nullptr);
 
         // ---- Dx: -dHy/dz (rows 0..Ny-1), then +dHz/dy (planes 1..Nz-1), then the source
-        {
-            P d = ldv<T, V>(a.D[0] + idx);
-            apply_uniform<-1, T, V>(d, diff<T, V>(hy, hy_km), row_lt ? t.m_lt : 0u, zk, lk, face_z, 0, a.dtd[2], a.dt,
-                                    a.phE[0][2][0] + ((size_t)lk * a.ny1 + j) * px + i0,
-                                    a.phE[0][2][1] + ((size_t)lk * a.ny1 + j) * px + i0);
-            apply_uniform<+1, T, V>(d, diff<T, V>(hz, hz_jm), pl_in ? t.m_lt : 0u, zy, ly, face_y, 0, a.dtd[1], a.dt,
-                                    a.phE[0][1][0] + ((size_t)kl * a.np[1][0] + ly) * px + i0,
-                                    a.phE[0][1][1] + ((size_t)kl * a.np[1][1] + ly) * px + i0);
-            if (a.src_on && k == a.kJ) {
-                const P m = ldv<T, V>(a.mag + (size_t)j * px + i0);
+        if (row_lt) term_u<-1, T, V>(dx, diff<T, V>(hy, hy_km), false, zk, lk, face_z, 0, a.dtd[2], a.dt,
+                                     a.phE[0][2][0] + ((size_t)lk * a.ny1 + j) * px + i0, a.phE[0][2][1] + ((size_t)lk * a.ny1 + j) * px + i0);
+        if (pl_in) term_u<+1, T, V>(dx, diff<T, V>(hz, hz_jm), false, zy, ly, face_y, 0, a.dtd[1], a.dt,
+                                    a.phE[0][1][0] + ((size_t)kl * a.np[1][0] + ly) * px + i0, a.phE[0][1][1] + ((size_t)kl * a.np[1][1] + ly) * px + i0);
+        if (a.src_on && k == a.kJ) {
+            const P m = ldv<T, V>(a.mag + (size_t)j * px + i0);
 #pragma unroll
-                for (int e = 0; e < V; ++e) if (t.m_lt & (1u << e)) d.v[e] = d.v[e] + a.jx * m.v[e];
-            }
-            stv<T, V>(a.D[0] + idx, d);
-            stv<T, V>(a.E[0] + idx, divide<T, V>(d, ldv<T, V>(a.eps[0] + idx)));
+            for (int e = 0; e < V; ++e) dx.v[e] = dx.v[e] + a.jx * m.v[e];
         }
+        stv<T, V>(a.D[0] + idx, dx);
+        if (!LEAN) stv<T, V>(a.E[0] + idx, divide<T, V>(dx, ex));
         // ---- Dy: +dHx/dz (columns 1..Nx-1), then -dHz/dx (planes 1..Nz-1)
         if (row_lt) {
-            P d = ldv<T, V>(a.D[1] + idx);
-            apply_uniform<+1, T, V>(d, diff<T, V>(hx, hx_km), t.m_in, zk, lk, face_z, 0, a.dtd[2], a.dt,
-                                    a.phE[1][2][0] + ((size_t)lk * a.ny1 + j) * px + i0,
-                                    a.phE[1][2][1] + ((size_t)lk * a.ny1 + j) * px + i0);
-            apply_x<-1, false, true, T, V>(d, diff_back_x<T, V>(hz, hz_l), pl_in ? t.m_lt : 0u, i0, Nx, a.np[0][0], a.np[0][1], a.xrow, px,
-                                     a.dtd[0], a.dt, t.lane_n ? a.phE[1][0][0] + row_n : nullptr, t.lane_p ? a.phE[1][0][1] + row_p : nullptr);
-            stv<T, V>(a.D[1] + idx, d);
-            stv<T, V>(a.E[1] + idx, divide<T, V>(d, ldv<T, V>(a.eps[1] + idx)));
+            term_u<+1, T, V>(dy, diff<T, V>(hx, hx_km), t.first, zk, lk, face_z, 0, a.dtd[2], a.dt,
+                             a.phE[1][2][0] + ((size_t)lk * a.ny1 + j) * px + i0, a.phE[1][2][1] + ((size_t)lk * a.ny1 + j) * px + i0);
+            if (pl_in) term_x<-1, T, V>(dy, diff_back_x<T, V>(hz, hz_l), t, a.dt, phx);
+            stv<T, V>(a.D[1] + idx, dy);
+            if (!LEAN) stv<T, V>(a.E[1] + idx, divide<T, V>(dy, ey));
         }
         // ---- Dz: +dHy/dx (rows 1..Ny-1), then -dHx/dy (columns 1..Nx-1); planes 0..Nz-1
         if (pl_lt) {
-            P d = ldv<T, V>(a.D[2] + idx);
-            apply_x<+1, false, true, T, V>(d, diff_back_x<T, V>(hy, hy_l), row_in ? t.m_lt : 0u, i0, Nx, a.np[0][0], a.np[0][1], a.xrow, px,
-                                     a.dtd[0], a.dt, t.lane_n ? a.phE[2][0][0] + row_n : nullptr, t.lane_p ? a.phE[2][0][1] + row_p : nullptr);
-            apply_uniform<-1, T, V>(d, diff<T, V>(hx, hx_jm), t.m_in, zy, ly, face_y, 0, a.dtd[1], a.dt,
-                                    a.phE[2][1][0] + ((size_t)kl * a.np[1][0] + ly) * px + i0,
-                                    a.phE[2][1][1] + ((size_t)kl * a.np[1][1] + ly) * px + i0);
-            stv<T, V>(a.D[2] + idx, d);
-            stv<T, V>(a.E[2] + idx, divide<T, V>(d, ldv<T, V>(a.eps[2] + idx)));
+            if (row_in) term_x<+1, T, V>(dz, diff_back_x<T, V>(hy, hy_l), t, a.dt, phx2);
+            term_u<-1, T, V>(dz, diff<T, V>(hx, hx_jm), t.first, zy, ly, face_y, 0, a.dtd[1], a.dt,
+                             a.phE[2][1][0] + ((size_t)kl * a.np[1][0] + ly) * px + i0, a.phE[2][1][1] + ((size_t)kl * a.np[1][1] + ly) * px + i0);
+            stv<T, V>(a.D[2] + idx, dz);
+            if (!LEAN) stv<T, V>(a.E[2] + idx, divide<T, V>(dz, ez));
         }
         hx_km = hx; hy_km = hy;
     }
@@ -288,16 +356,15 @@ __global__ void __launch_bounds__(256) k3_half_e(const K3<T> a) {
 
 // ------------------------------------------------------------------ H-half --
 // B -= curl E (CPML folded in), H = B/mu0 (or B/mu).
-template <typename T, bool MU>
+template <typename T, bool MU, bool LEAN>
 __global__ void __launch_bounds__(256) k3_half_h(const K3<T> a) {
     constexpr int V = VecWidth<T>::V;
     using P = Pack<T, V>;
-    const Tile3<T> t = decode_tile(a);
+    const Lane3<T, V> t = decode_lane<T, V, true>(a);
     if (!t.ok) return;
     const int j = t.j, i0 = t.i0, lane = t.lane;
     const size_t sz = (size_t)a.ny1 * a.px;
-    const int Nx = a.Nx, Ny = a.Ny, Nz = a.Nz, px = a.px;
-    const T* __restrict__ Ex = a.E[0]; const T* __restrict__ Ey = a.E[1]; const T* __restrict__ Ez = a.E[2];
+    const int Ny = a.Ny, Nz = a.Nz, px = a.px;
 
     int ly;
     const int zy = zone_h(j, Ny, a.np[1][0], a.np[1][1], true, ly);
@@ -306,7 +373,7 @@ __global__ void __launch_bounds__(256) k3_half_h(const K3<T> a) {
     const bool row_lt = j < Ny, row_in = j >= 1 && j < Ny;
 
     size_t idx = ((size_t)t.klb * a.ny1 + j) * px + i0;
-    P ex = ldv<T, V>(Ex + idx), ey = ldv<T, V>(Ey + idx);
+    P ex = load_e<T, V, LEAN>(a, 0, idx), ey = load_e<T, V, LEAN>(a, 1, idx);
 
     for (int kl = t.klb; kl < t.kle; ++kl, idx += sz) {
         const int k = kl + a.zoff;
@@ -315,49 +382,52 @@ __global__ void __launch_bounds__(256) k3_half_h(const K3<T> a) {
         const bool pl_lt = k < Nz, pl_in = k >= 1 && k < Nz;
 
         P ex_kp = zero_pack<T, V>(), ey_kp = zero_pack<T, V>();
-        if (kl + 1 < a.nzp) { ex_kp = ldv<T, V>(Ex + idx + sz); ey_kp = ldv<T, V>(Ey + idx + sz); }
-        const P ez = ldv<T, V>(Ez + idx);
+        if (kl + 1 < a.nzp) { ex_kp = load_e<T, V, LEAN>(a, 0, idx + sz); ey_kp = load_e<T, V, LEAN>(a, 1, idx + sz); }
+        const P ez = load_e<T, V, LEAN>(a, 2, idx);
         P ex_jp = zero_pack<T, V>(), ez_jp = zero_pack<T, V>();
-        if (row_lt) { ex_jp = ldv<T, V>(Ex + idx + px); ez_jp = ldv<T, V>(Ez + idx + px); }
-        const T ey_r = right_of<T, V>(ey, Ey + idx, i0, lane, px);
-        const T ez_r = right_of<T, V>(ez, Ez + idx, i0, lane, px);
+        if (row_lt) { ex_jp = load_e<T, V, LEAN>(a, 0, idx + px); ez_jp = load_e<T, V, LEAN>(a, 2, idx + px); }
+        P bx = ldv<T, V>(a.B[0] + idx), by = ldv<T, V>(a.B[1] + idx), bz = ldv<T, V>(a.B[2] + idx);
+        P mx = zero_pack<T, V>(), my = mx, mz = mx;
+        if (MU && !LEAN) { mx = ldv<T, V>(a.mu[0] + idx); my = ldv<T, V>(a.mu[1] + idx); mz = ldv<T, V>(a.mu[2] + idx); }
 
-        const size_t row_n = ((size_t)kl * a.ny1 + j) * a.xwn + i0;
-        const size_t row_p = ((size_t)kl * a.ny1 + j) * a.xwp + (i0 - a.xp0);
+        T ey_r = __shfl_down(ey.v[0], 1), ez_r = __shfl_down(ez.v[0], 1);
+        if (lane == kLanes - 1) {
+            ey_r = i0 + V < px ? load_e1<T, LEAN>(a, 1, idx + V) : (T)0;
+            ez_r = i0 + V < px ? load_e1<T, LEAN>(a, 2, idx + V) : (T)0;
+        }
+        T* phx1 = t.in_n ? a.phM[1][0][0] + ((size_t)kl * a.ny1 + j) * a.xwn + i0
+                         : (t.in_p ? a.phM[1][0][1] + ((size_t)kl * a.ny1 + j) * a.xwp + (i0 - a.xp0) : nullptr);
+        T* phx2 = t.in_n ? a.phM[2][0][0] + ((size_t)kl * a.ny1 + j) * a.xwn + i0
+                         : (t.in_p ? a.phM[2][0][1] + ((size_t)kl * a.ny1 + j) * a.xwp + (i0 - a.xp0) : nullptr);
 
         // ---- Bx: +dEy/dz, then -dEz/dy; columns 1..Nx-1, rows 0..Ny-1, planes 0..Nz-1
         if (row_lt && pl_lt) {
-            P b = ldv<T, V>(a.B[0] + idx);
-            apply_uniform<+1, T, V>(b, diff<T, V>(ey_kp, ey), t.m_in, zk, lk, face_z, 3, a.dtd[2], a.dt,
-                                    a.phM[0][2][0] + ((size_t)lk * a.ny1 + j) * px + i0,
-                                    a.phM[0][2][1] + ((size_t)lk * a.ny1 + j) * px + i0);
-            apply_uniform<-1, T, V>(b, diff<T, V>(ez_jp, ez), t.m_in, zy, ly, face_y, 3, a.dtd[1], a.dt,
-                                    a.phM[0][1][0] + ((size_t)kl * a.np[1][0] + ly) * px + i0,
-                                    a.phM[0][1][1] + ((size_t)kl * a.np[1][1] + ly) * px + i0);
-            stv<T, V>(a.B[0] + idx, b);
-            stv<T, V>(a.H[0] + idx, MU ? divide<T, V>(b, ldv<T, V>(a.mu[0] + idx)) : divide<T, V>(b, a.mu0));
+            term_u<+1, T, V>(bx, diff<T, V>(ey_kp, ey), t.first, zk, lk, face_z, 3, a.dtd[2], a.dt,
+                             a.phM[0][2][0] + ((size_t)lk * a.ny1 + j) * px + i0, a.phM[0][2][1] + ((size_t)lk * a.ny1 + j) * px + i0);
+            term_u<-1, T, V>(bx, diff<T, V>(ez_jp, ez), t.first, zy, ly, face_y, 3, a.dtd[1], a.dt,
+                             a.phM[0][1][0] + ((size_t)kl * a.np[1][0] + ly) * px + i0, a.phM[0][1][1] + ((size_t)kl * a.np[1][1] + ly) * px + i0);
+            stv<T, V>(a.B[0] + idx, bx);
+            if (!LEAN) stv<T, V>(a.H[0] + idx, MU ? divide<T, V>(bx, mx) : divide<T, V>(bx, a.mu0));
         }
         // ---- By: +dEz/dx, then -dEx/dz; rows 1..Ny-1 (row 0 and Ny only take H = B/mu), planes 0..Nz-1
         if (pl_lt) {
-            P b = ldv<T, V>(a.B[1] + idx);
-            apply_x<+1, true, true, T, V>(b, diff_fwd_x<T, V>(ez, ez_r), row_in ? t.m_lt : 0u, i0, Nx, a.np[0][0], a.np[0][1], a.xrow, px,
-                                    a.dtd[0], a.dt, t.lane_n ? a.phM[1][0][0] + row_n : nullptr, t.lane_p ? a.phM[1][0][1] + row_p : nullptr);
-            apply_uniform<-1, T, V>(b, diff<T, V>(ex_kp, ex), row_in ? t.m_lt : 0u, zk, lk, face_z, 3, a.dtd[2], a.dt,
-                                    a.phM[1][2][0] + ((size_t)lk * a.ny1 + j) * px + i0,
-                                    a.phM[1][2][1] + ((size_t)lk * a.ny1 + j) * px + i0);
-            stv<T, V>(a.B[1] + idx, b);
-            stv<T, V>(a.H[1] + idx, MU ? divide<T, V>(b, ldv<T, V>(a.mu[1] + idx)) : divide<T, V>(b, a.mu0));
+            if (row_in) {
+                term_x<+1, T, V>(by, diff_fwd_x<T, V>(ez, ez_r), t, a.dt, phx1);
+                term_u<-1, T, V>(by, diff<T, V>(ex_kp, ex), false, zk, lk, face_z, 3, a.dtd[2], a.dt,
+                                 a.phM[1][2][0] + ((size_t)lk * a.ny1 + j) * px + i0, a.phM[1][2][1] + ((size_t)lk * a.ny1 + j) * px + i0);
+            }
+            stv<T, V>(a.B[1] + idx, by);
+            if (!LEAN) stv<T, V>(a.H[1] + idx, MU ? divide<T, V>(by, my) : divide<T, V>(by, a.mu0));
         }
         // ---- Bz: +dEx/dy, then -dEy/dx; rows 0..Ny-1, planes 1..Nz-1 (planes 0 and Nz only take H = B/mu)
         if (row_lt) {
-            P b = ldv<T, V>(a.B[2] + idx);
-            apply_uniform<+1, T, V>(b, diff<T, V>(ex_jp, ex), pl_in ? t.m_lt : 0u, zy, ly, face_y, 3, a.dtd[1], a.dt,
-                                    a.phM[2][1][0] + ((size_t)kl * a.np[1][0] + ly) * px + i0,
-                                    a.phM[2][1][1] + ((size_t)kl * a.np[1][1] + ly) * px + i0);
-            apply_x<-1, true, true, T, V>(b, diff_fwd_x<T, V>(ey, ey_r), pl_in ? t.m_lt : 0u, i0, Nx, a.np[0][0], a.np[0][1], a.xrow, px,
-                                    a.dtd[0], a.dt, t.lane_n ? a.phM[2][0][0] + row_n : nullptr, t.lane_p ? a.phM[2][0][1] + row_p : nullptr);
-            stv<T, V>(a.B[2] + idx, b);
-            stv<T, V>(a.H[2] + idx, MU ? divide<T, V>(b, ldv<T, V>(a.mu[2] + idx)) : divide<T, V>(b, a.mu0));
+            if (pl_in) {
+                term_u<+1, T, V>(bz, diff<T, V>(ex_jp, ex), false, zy, ly, face_y, 3, a.dtd[1], a.dt,
+                                 a.phM[2][1][0] + ((size_t)kl * a.np[1][0] + ly) * px + i0, a.phM[2][1][1] + ((size_t)kl * a.np[1][1] + ly) * px + i0);
+                term_x<-1, T, V>(bz, diff_fwd_x<T, V>(ey, ey_r), t, a.dt, phx2);
+            }
+            stv<T, V>(a.B[2] + idx, bz);
+            if (!LEAN) stv<T, V>(a.H[2] + idx, MU ? divide<T, V>(bz, mz) : divide<T, V>(bz, a.mu0));
         }
         ex = ex_kp; ey = ey_kp;
     }

@@ -1,0 +1,94 @@
+"""Properties at sizes no CPU oracle reaches (BASELINE configs 3-5 geometry, reduced step counts).
+
+Bit-exactness is carried by order-independent checksums (value bits mixed with the cell index):
+lean storage == full storage, slabs == whole grid, launch shape (planes per workgroup, tile order)
+never changes a bit; plus the reference's own sanity heuristics (all finite, no blow-up)."""
+import numpy as np
+import pytest
+
+import fdtd_amd
+from fdtd_amd import engine as E
+from fdtd_amd import setup as fs
+from fdtd_amd import slab
+
+pytestmark = pytest.mark.gpu
+FIELDS = (E.DX, E.DY, E.DZ, E.BX, E.BY, E.BZ)
+
+
+def make(N, npml, mode, has_mu, z_range=None, steps=64, dipole=False):
+    K = fs.constants()
+    d = (1053e-9 / 20,) * 3
+    dt = d[0] / (2 * K["c0"])
+    eng = fdtd_amd.Engine3D(N, npml, d, dt, K["mu0"], N[2] // 2 if dipole else 20, steps, precision=32, has_mu=has_mu, mode=mode, z_range=z_range)
+    fs.load_cpml3d(eng, d, dt)
+    wf, mag = fs.default_source3d(N[0], N[1], steps, d, dt)
+    if dipole:
+        mag[:] = 0
+        mag[N[0] // 2, N[1] // 2] = 1.0
+    eng.set(E.JX_WF, wf)
+    eng.set(E.JX_MAG, mag)
+    if has_mu:
+        eng.fill_materials(1234, K["eps0"], 4 * K["eps0"], K["mu0"], 2 * K["mu0"])
+    else:
+        eng.fill_materials(1234, K["eps0"], K["eps0"], K["mu0"], K["mu0"])     # vacuum
+    return eng
+
+
+def test_vacuum_cavity_512_lean_equals_full_and_stays_bounded():
+    """BASELINE config 3: 512^3 vacuum cavity (no CPML), dipole source."""
+    N, steps = (512, 512, 512), 24
+    sums = {}
+    for mode in (E.MODE_FULL, E.MODE_LEAN):
+        eng = make(N, (0,) * 6, mode, False, steps=steps, dipole=True)
+        eng.step(0, steps)
+        sums[mode] = [eng.checksum(i) for i in FIELDS]
+        energy = [eng.sumsq(i) for i in FIELDS]
+        assert all(np.isfinite(energy)) and energy[0] > 0
+        eng.close()
+    assert sums[E.MODE_FULL] == sums[E.MODE_LEAN]
+
+
+def test_hetero_cpml_slabs_equal_whole_grid_384():
+    """BASELINE config 4 geometry (eps/mu grids, 20-layer CPML) at 384x384x512: 4 slabs == whole grid,
+    and the launch shape does not change a bit."""
+    N, steps = (384, 384, 512), 12
+    whole = make(N, (20,) * 6, E.MODE_LEAN, True, steps=steps)
+    whole.step(0, steps // 2)
+    whole.tune(3, 0)
+    whole.step(steps // 2, steps - steps // 2)
+    want = [whole.checksum(i) for i in FIELDS]
+    e_whole = whole.sumsq(E.DX)
+    whole.close()
+    parts = slab.partition(N[2], 4)
+    engs = [make(N, (20,) * 6, E.MODE_LEAN, True, z_range=p, steps=steps) for p in parts]
+    pl = [{w: [E.halo_tensor(e, w, c) for c in (0, 1)] for w in range(4)} for e in engs]
+    for n in range(steps):
+        for e in engs:
+            e.half_e(n, E.PART_INTERIOR)
+            e.half_e(n, E.PART_EDGE)
+        for r in range(1, 4):
+            for c in (0, 1):
+                pl[r - 1][E.HALO_RECV_HI][c].copy_(pl[r][E.HALO_SEND_DOWN][c])
+        for e in engs:
+            e.half_h(E.PART_INTERIOR)
+            e.half_h(E.PART_EDGE)
+        for r in range(3):
+            for c in (0, 1):
+                pl[r + 1][E.HALO_RECV_LO][c].copy_(pl[r][E.HALO_SEND_UP][c])
+    got = [sum(e.checksum(i) for e in engs) % 2 ** 64 for i in FIELDS]
+    assert got == want
+    assert abs(sum(e.sumsq(E.DX) for e in engs) / e_whole - 1) < 1e-12
+
+
+def test_energy_growth_heuristic_1024_plane_source():
+    """The reference's verify_vti heuristic (energy growth ratio between frames within [0.1, 100],
+    nothing non-finite) on a 1024 x 1024 x 256 slab of the headline workload, taken after the
+    source's 200-step ramp so that the ratio measures propagation, not the ramp."""
+    N, steps = (1024, 1024, 256), 260
+    eng = make(N, (20,) * 6, E.MODE_LEAN, True, steps=steps)
+    eng.step(0, 220)
+    e1 = eng.sumsq(E.DX)
+    eng.step(220, 40)
+    e2 = eng.sumsq(E.DX)
+    assert np.isfinite(e1) and np.isfinite(e2) and e1 > 0
+    assert 0.1 < e2 / e1 < 100

@@ -51,6 +51,25 @@ def test_fp32_engine_equals_fp32_twin_3d(name):
             assert util.family_rel_l2([got[(step, i)] for i in ids], [outs[(step, i)] for i in ids]) < (1e-6 if fam < 2 else 3e-6)
 
 
+@pytest.mark.parametrize("name", FIX3D)
+@pytest.mark.parametrize("prec", [32, 64])
+def test_lean_storage_equals_full_storage_3d(name, prec):
+    """Lean storage (E = D/eps, H = B/mu recomputed where consumed) must give the same bits:
+    fp64 against the reference vectors, fp32 against the fp32 twin."""
+    meta, ins, outs, _ = util.load_fixture(name)
+    eng = engine3d_from_meta(meta, prec, mode=fdtd_amd.engine.MODE_LEAN)
+    util.feed(eng, ins)
+    got = util.run_snapshots(eng, meta, outs)
+    if prec == 64:
+        ref = outs
+    else:
+        tw = util.twin3d_from_meta(meta, 32)
+        util.feed(tw, ins)
+        ref = util.run_snapshots(tw, meta, outs)
+    for key in outs:
+        util.assert_equal_arrays(got[key], ref[key], f"{name} lean fp{prec} step {key[0]} array {key[1]}")
+
+
 def test_probe_series_matches_reference_3d():
     meta, ins, outs, extra = util.load_fixture("g2_3d_cavity")
     eng = engine3d_from_meta(meta, 64)
@@ -64,12 +83,13 @@ def test_probe_series_matches_reference_3d():
     util.assert_equal_arrays(np.array(probe), extra["probe"], "probe series")
 
 
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("prec", [32, 64])
-def test_mu_grid_3d(prec):
+def test_mu_grid_3d(prec, mode):
     """Heterogeneous mu has no reference counterpart: checked against the twin, and mu == mu0 must
     reproduce the reference vectors."""
     meta, ins, outs, _ = util.load_fixture("g3_3d_hetero")
-    eng = engine3d_from_meta(meta, prec, has_mu=True)
+    eng = engine3d_from_meta(meta, prec, has_mu=True, mode=mode)
     tw = util.twin3d_from_meta(meta, prec, has_mu=True)
     util.feed(eng, ins)
     util.feed(tw, ins)

@@ -1,0 +1,104 @@
+"""z-slab driver on CPU: partitioning, and the exchange choreography over gloo with two ranks.
+
+The stand-in engine below is a 1-D Yee line along z (one value per layer and component) with the
+same half_e/half_h(part) contract and ghost layers as the 3-D engine; two ranks exchanging ghosts
+through fdtd_amd.slab must reproduce the single-rank run bit for bit.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from fdtd_amd import slab
+
+
+def test_partition_is_contiguous_and_balanced():
+    for Nz, world in [(1024, 8), (1000, 7), (8, 8), (13, 4), (5, 1)]:
+        parts = slab.partition(Nz, world)
+        assert parts[0][0] == 0 and parts[-1][1] == Nz
+        assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+        sizes = [hi - lo for lo, hi in parts]
+        assert min(sizes) >= 1 and max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        slab.partition(3, 4)
+
+
+class Line:
+    """E(k), k in [0,Nz]; H(k), k in [0,Nz): E(k) += c (H(k) - H(k-1)) for 1 <= k < Nz, source at kJ;
+    H(k) += c (E(k+1) - E(k)).  Local storage: planes kl = 0..nzl+1, global k = z_lo - 1 + kl."""
+
+    def __init__(self, Nz, z_lo, z_hi, kJ):
+        self.Nz, self.z_lo, self.z_hi, self.kJ = Nz, z_lo, z_hi, kJ
+        self.nzl = z_hi - z_lo
+        self.last = z_hi == Nz
+        self.E = torch.zeros(self.nzl + 2, dtype=torch.float64)
+        self.H = torch.zeros(self.nzl + 2, dtype=torch.float64)
+        self.log = []
+
+    def _planes(self, part, electric):
+        lo, hi = 1, (self.nzl + 2 if self.last else self.nzl + 1)
+        if part == slab.PART_ALL:
+            return range(lo, hi)
+        if electric:
+            return range(lo, lo + 1) if part == slab.PART_EDGE else range(lo + 1, hi)
+        top = self.nzl
+        return range(top, top + 1) if part == slab.PART_EDGE else [p for p in range(lo, hi) if p != top]
+
+    def half_e(self, n, part, stream=None):
+        for kl in self._planes(part, True):
+            k = self.z_lo - 1 + kl
+            if 1 <= k < self.Nz:
+                self.E[kl] = self.E[kl] + 0.5 * (self.H[kl] - self.H[kl - 1])
+            if k == self.kJ:
+                self.E[kl] = self.E[kl] + np.sin(0.3 * (n + 1))
+
+    def half_h(self, part, stream=None):
+        for kl in self._planes(part, False):
+            k = self.z_lo - 1 + kl
+            if k < self.Nz:
+                self.H[kl] = self.H[kl] + 0.5 * (self.E[kl + 1] - self.E[kl])
+
+
+def _worker(rank, world, port, Nz, steps, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z_lo, z_hi = slab.partition(Nz, world)[rank]
+    eng = Line(Nz, z_lo, z_hi, kJ=3)
+    x = slab.HaloExchange(rank, world, [eng.H[eng.nzl:eng.nzl + 1]], [eng.H[0:1]], [eng.E[1:2]], [eng.E[eng.nzl + 1:eng.nzl + 2]])
+    st = slab.SlabStepper(eng, x)
+    st.run(0, steps)
+    st.finish()
+    owned_e = eng.E[1:eng.nzl + 1 + (1 if eng.last else 0)].clone()
+    owned_h = eng.H[1:eng.nzl + 1].clone()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (owned_e.numpy(), owned_h.numpy()))
+    if rank == 0:
+        np.save(out + "_e.npy", np.concatenate([g[0] for g in gathered]))
+        np.save(out + "_h.npy", np.concatenate([g[1] for g in gathered]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_rank_exchange_reproduces_single_rank(tmp_path, world):
+    Nz, steps = 23, 40
+    ref = Line(Nz, 0, Nz, kJ=3)
+    for n in range(steps):
+        ref.half_e(n, slab.PART_ALL)
+        ref.half_h(slab.PART_ALL)
+    out = str(tmp_path / "slab")
+    mp.spawn(_worker, args=(world, _free_port(), Nz, steps, out), nprocs=world, join=True)
+    e, h = np.load(out + "_e.npy"), np.load(out + "_h.npy")
+    assert np.array_equal(e, ref.E[1:Nz + 2].numpy())
+    assert np.array_equal(h, ref.H[1:Nz + 1].numpy())
+    assert np.abs(e).max() > 0.1
