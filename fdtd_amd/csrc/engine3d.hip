@@ -93,7 +93,7 @@ struct fdtd3d_engine {
     virtual int halo(int which, int comp, void** p, size_t* bytes) = 0;
     virtual int reduce(int id, double* sumsq, uint64_t* checksum, hipStream_t s) = 0;
     virtual size_t device_bytes() = 0;
-    virtual int tune(int chunk, int remap) = 0;
+    virtual int tune(int chunk, int remap, int rows) = 0;
     fdtd3d_desc d;
     KernelTimer timer;
 };
@@ -118,7 +118,7 @@ struct Engine3 : fdtd3d_engine {
     double* red_d = nullptr;          // reduction scratch: 1024 partial sums + checksum word
     std::vector<double> tab_h;        // [3][2][6][kMaxLayers], fp64 master copy
     std::vector<T> wf;
-    int chunk = 8, remap = 1;
+    int chunk = 8, remap = 1, wpb = 4;
     std::vector<void*> allocs;
 
     ~Engine3() override {
@@ -152,6 +152,7 @@ struct Engine3 : fdtd3d_engine {
         xwp = np[0][1] > 0 ? round_up(d.Nx - xp0, 4) : 0;
         if (const char* e = getenv("FDTD_Z_CHUNK")) { int c = atoi(e); if (c >= 1 && c <= 4096) chunk = c; }
         if (const char* e = getenv("FDTD_XCD_REMAP")) remap = atoi(e) != 0;
+        if (const char* e = getenv("FDTD_ROWS_PER_GROUP")) { int w = atoi(e); if (w >= 1 && w <= 4) wpb = w; }
 
         int rc;
         for (int f = 0; f < 6; ++f) for (int c = 0; c < 3; ++c) {
@@ -191,9 +192,10 @@ struct Engine3 : fdtd3d_engine {
     }
 
     size_t device_bytes() override { return bytes; }
-    int tune(int c, int r) override {
+    int tune(int c, int r, int w) override {
         if (c >= 1 && c <= 4096) chunk = c;
         if (r == 0 || r == 1) remap = r;
+        if (w >= 1 && w <= 4) wpb = w;
         return FDTD_OK;
     }
 
@@ -420,7 +422,7 @@ struct Engine3 : fdtd3d_engine {
         a.xwn = xwn; a.xwp = xwp; a.xp0 = xp0;
         a.kJ = d.k_Jx; a.src_on = 0; a.jx = (T)0;
         a.dt = (T)d.dt; a.dtd[0] = (T)(d.dt / d.dx); a.dtd[1] = (T)(d.dt / d.dy); a.dtd[2] = (T)(d.dt / d.dz); a.mu0 = (T)d.mu0;
-        a.nbx = px / (kLanes * V); a.nby = (ny1 + kWavesPerBlock - 1) / kWavesPerBlock;
+        a.nbx = px / (kLanes * V); a.nby = (ny1 + wpb - 1) / wpb; a.wpb = wpb;
         a.chunk = chunk;
         a.remap = remap;
         return a;
@@ -446,7 +448,7 @@ struct Engine3 : fdtd3d_engine {
         a.nbz = (kl1 - kl0 + a.chunk - 1) / a.chunk;
         const unsigned nblk = (unsigned)a.nbx * a.nby * a.nbz;
         timer.begin(kind, s);
-        hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(kLanes * wpb), 0, s, a);
         timer.end(s);
         FDTD_HIP(hipGetLastError());
         return FDTD_OK;
@@ -567,7 +569,7 @@ int fdtd3d_halo(fdtd3d_handle h, int which, int comp, void** p, size_t* bytes) {
 int fdtd3d_sumsq(fdtd3d_handle h, int id, double* out, void* stream) { return h ? h->reduce(id, out, nullptr, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
 int fdtd3d_checksum(fdtd3d_handle h, int id, uint64_t* out, void* stream) { return h ? h->reduce(id, nullptr, out, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
 size_t fdtd3d_device_bytes(fdtd3d_handle h) { return h ? h->device_bytes() : 0; }
-int fdtd3d_tune(fdtd3d_handle h, int chunk, int remap) { return h ? h->tune(chunk, remap) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_tune(fdtd3d_handle h, int chunk, int remap, int rows) { return h ? h->tune(chunk, remap, rows) : fail(FDTD_ERR_ARG, "null handle"); }
 int fdtd3d_kernel_timing(fdtd3d_handle h, int enable) {
     if (!h) return fail(FDTD_ERR_ARG, "null handle");
     h->timer.enabled = enable != 0;

@@ -47,6 +47,7 @@ struct K3 {
     int chunk;         // planes per workgroup
     int nbx, nby, nbz;
     int remap;         // 1: hand each XCD a contiguous range of tiles
+    int wpb;           // waves (= rows) per workgroup
 };
 
 template <typename T, int V>
@@ -191,7 +192,7 @@ __device__ __forceinline__ Lane3<T, V> decode_lane(const K3<T>& a) {
     const int by = bid % a.nby;
     const int bz = bid / a.nby;
     t.i0 = (bx * kLanes + t.lane) * V;
-    t.j = by * kWavesPerBlock + w;
+    t.j = by * a.wpb + w;
     t.klb = a.kl0 + bz * a.chunk;
     t.kle = min(t.klb + a.chunk, a.kl1);
     t.ok = t.j < a.ny1;

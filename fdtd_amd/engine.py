@@ -167,8 +167,8 @@ class Engine3D(_Common):
         _check(lib().fdtd3d_halo(self.h, C.c_int(which), C.c_int(comp), C.byref(p), C.byref(n)), "fdtd3d_halo")
         return p.value, n.value
 
-    def tune(self, chunk: int = 0, remap: int = -1) -> None:
-        _check(lib().fdtd3d_tune(self.h, C.c_int(chunk), C.c_int(remap)), "fdtd3d_tune")
+    def tune(self, chunk: int = 0, remap: int = -1, rows: int = 0) -> None:
+        _check(lib().fdtd3d_tune(self.h, C.c_int(chunk), C.c_int(remap), C.c_int(rows)), "fdtd3d_tune")
 
     def checksum(self, id_: int, stream=None) -> int:
         v = C.c_uint64(0)

@@ -143,10 +143,11 @@ int fdtd3d_checksum(fdtd3d_handle h, int id, uint64_t* out, void* stream);
 /* Bytes of device memory held by the handle. */
 size_t fdtd3d_device_bytes(fdtd3d_handle h);
 
-/* Launch-shape knobs (no effect on results): planes marched per workgroup (1..4096, other values
- * keep the current setting) and XCD-contiguous tile order (0/1).  Defaults 8 and 1; the
- * environment variables FDTD_Z_CHUNK / FDTD_XCD_REMAP set them at creation. */
-int fdtd3d_tune(fdtd3d_handle h, int chunk, int remap);
+/* Launch-shape knobs (no effect on results): planes marched per workgroup (1..4096), XCD-contiguous
+ * tile order (0/1), rows (= waves) per workgroup (1..4); a value outside its range keeps the
+ * current setting.  The environment variables FDTD_Z_CHUNK / FDTD_XCD_REMAP / FDTD_ROWS_PER_GROUP
+ * set them at creation. */
+int fdtd3d_tune(fdtd3d_handle h, int chunk, int remap, int rows);
 
 /* Timing hook for the dominant kernels: if enabled, every E-half / H-half launch is
  * bracketed by HIP events on its stream; fdtd3d_kernel_time() synchronises and returns
