@@ -2,6 +2,7 @@
 #include "kernels2d.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -24,6 +25,17 @@ __global__ void k2_sumsq(const T* arr, int Nx, int px, int rows, double* partial
     for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
 }
+// acc(k,i) (+)= Ey(i,k)^2 * weight, device layout [k][px]
+template <typename T>
+__global__ void k2_observe(const T* ey, T* acc, int Nx, int Nz, int px, T weight, int reset) {
+    const size_t total = (size_t)Nz * px;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        if ((int)(t % px) >= Nx) continue;
+        const T e = ey[t];
+        const T old = reset ? (T)0 : acc[t];
+        acc[t] = old + e * e * weight;
+    }
+}
 }  // namespace fdtd
 
 struct fdtd2d_engine {
@@ -34,6 +46,8 @@ struct fdtd2d_engine {
     virtual int step(int n0, int count, hipStream_t s) = 0;
     virtual int sumsq(int id, double* out, hipStream_t s) = 0;
     virtual size_t device_bytes() = 0;
+    virtual int observe_accumulate(double weight, int reset, hipStream_t s) = 0;
+    virtual int observe_rms(double* host, size_t n) = 0;
     fdtd2d_desc d;
     KernelTimer timer;
 };
@@ -97,6 +111,23 @@ struct Engine2 : fdtd2d_engine {
         return FDTD_OK;
     }
     size_t device_bytes() override { return bytes; }
+    T* obs_acc = nullptr;
+    int observe_accumulate(double weight, int reset, hipStream_t s) override {
+        int rc;
+        if (!obs_acc && (rc = dalloc((void**)&obs_acc, fsize * sizeof(T)))) return rc;
+        hipLaunchKernelGGL(k2_observe<T>, dim3(2048), dim3(256), 0, s, Fa[0], obs_acc, d.Nx, d.Nz, px, (T)weight, reset);
+        FDTD_HIP(hipGetLastError());
+        return FDTD_OK;
+    }
+    int observe_rms(double* host, size_t n) override {
+        if (n != (size_t)d.Nx * d.Nz || !host) return fail(FDTD_ERR_ARG, "observe_rms: expected %zu values", (size_t)d.Nx * d.Nz);
+        if (!obs_acc) return fail(FDTD_ERR_STATE, "observe_rms: nothing accumulated yet");
+        FDTD_HIP(hipDeviceSynchronize());
+        std::vector<T> st(fsize);
+        FDTD_HIP(hipMemcpy(st.data(), obs_acc, st.size() * sizeof(T), hipMemcpyDeviceToHost));
+        for (int i = 0; i < d.Nx; ++i) for (int k = 0; k < d.Nz; ++k) host[(size_t)i * d.Nz + k] = std::sqrt((double)st[(size_t)k * px + i]);
+        return FDTD_OK;
+    }
 
     struct Map { int n0 = 0, n1 = 0; T* dev = nullptr; size_t dev_elems = 0; int kind = -1, s = 0; bool mag = false; };
     bool make_map(int id, Map& m) {
@@ -281,6 +312,8 @@ int fdtd2d_get_array(fdtd2d_handle h, int id, double* host, size_t n) { return h
 int fdtd2d_step(fdtd2d_handle h, int n0, int count, void* stream) { return h ? h->step(n0, count, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
 int fdtd2d_sumsq(fdtd2d_handle h, int id, double* out, void* stream) { return (h && out) ? h->sumsq(id, out, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null argument"); }
 size_t fdtd2d_device_bytes(fdtd2d_handle h) { return h ? h->device_bytes() : 0; }
+int fdtd2d_observe_accumulate(fdtd2d_handle h, double weight, int reset, void* stream) { return h ? h->observe_accumulate(weight, reset, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd2d_observe_rms(fdtd2d_handle h, double* host, size_t n) { return h ? h->observe_rms(host, n) : fail(FDTD_ERR_ARG, "null handle"); }
 int fdtd2d_kernel_timing(fdtd2d_handle h, int enable) { if (!h) return fail(FDTD_ERR_ARG, "null handle"); h->timer.enabled = enable != 0; return FDTD_OK; }
 int fdtd2d_kernel_time(fdtd2d_handle h, int kind, int* launches, double* total_ms) { return h ? h->timer.collect(kind, launches, total_ms) : fail(FDTD_ERR_ARG, "null handle"); }
 

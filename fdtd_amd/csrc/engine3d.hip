@@ -78,6 +78,34 @@ __global__ void k_reduce(const T* arr, CompGeom g, double* sumsq_partial, unsign
     if (threadIdx.x == 0) { sumsq_partial[blockIdx.x] = sh[0]; atomicAdd(checksum, shc[0]); }
 }
 
+
+// Cell-centre observables (FDTD3D::run / dumpFrame, FDTD3D.cpp:1023-1097): every cell averages the
+// four Ex, Ey, Ez samples on its edges.  MODE 0: acc (+)= (1/16)(sx^2 + sy^2 + sz^2) * weight, the
+// running RMS window; MODE 1: out0 = (1/4) sx (centred Ex), out1 = ax^2 + ay^2 + az^2 (|E|^2).
+// Output order is x fastest, then y, then z -- the order the reference hands to its VTI writer.
+template <typename T, bool LEAN, int MODE>
+__global__ void k3_observe(const K3<T> a, T* out0, T* out1, T weight, int reset, int nzl) {
+    const size_t cells = (size_t)a.Nx * a.Ny * nzl;
+    const size_t sz = (size_t)a.ny1 * a.px;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < cells; t += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(t % a.Nx), j = (int)((t / a.Nx) % a.Ny), kl = 1 + (int)(t / ((size_t)a.Nx * a.Ny));
+        const size_t id = ((size_t)kl * a.ny1 + j) * a.px + i;
+        const bool wall = i + 1 >= a.Nx;          // column Nx of Ey, Ez is the unstored zero wall
+        const T sx = load_e1<T, LEAN>(a, 0, id) + load_e1<T, LEAN>(a, 0, id + a.px) + load_e1<T, LEAN>(a, 0, id + sz) + load_e1<T, LEAN>(a, 0, id + sz + a.px);
+        const T sy = load_e1<T, LEAN>(a, 1, id) + (wall ? (T)0 : load_e1<T, LEAN>(a, 1, id + 1)) + load_e1<T, LEAN>(a, 1, id + sz) + (wall ? (T)0 : load_e1<T, LEAN>(a, 1, id + sz + 1));
+        const T s_z = load_e1<T, LEAN>(a, 2, id) + (wall ? (T)0 : load_e1<T, LEAN>(a, 2, id + 1)) + load_e1<T, LEAN>(a, 2, id + a.px) + (wall ? (T)0 : load_e1<T, LEAN>(a, 2, id + a.px + 1));
+        if (MODE == 0) {
+            const T e_sq = (T)0.0625 * (sx * sx + sy * sy + s_z * s_z);
+            const T old = reset ? (T)0 : out0[t];
+            out0[t] = old + e_sq * weight;
+        } else {
+            const T ax = (T)0.25 * sx, ay = (T)0.25 * sy, az = (T)0.25 * s_z;
+            out0[t] = ax;
+            out1[t] = ax * ax + ay * ay + az * az;
+        }
+    }
+}
+
 }  // namespace fdtd
 
 using namespace fdtd;
@@ -94,6 +122,9 @@ struct fdtd3d_engine {
     virtual int reduce(int id, double* sumsq, uint64_t* checksum, hipStream_t s) = 0;
     virtual size_t device_bytes() = 0;
     virtual int tune(int chunk, int remap, int rows) = 0;
+    virtual int observe_accumulate(double weight, int reset, hipStream_t s) = 0;
+    virtual int observe_rms(double* host, size_t n) = 0;
+    virtual int observe_frame(double* ex_center, double* e_mag, size_t n, hipStream_t s) = 0;
     fdtd3d_desc d;
     KernelTimer timer;
 };
@@ -116,6 +147,8 @@ struct Engine3 : fdtd3d_engine {
     T* xrow_d = nullptr;
     T* mag_d = nullptr;
     double* red_d = nullptr;          // reduction scratch: 1024 partial sums + checksum word
+    T* obs_acc = nullptr;             // RMS window accumulator, [owned layers][Ny][Nx]
+    T* obs_tmp = nullptr;             // two frame buffers of the same shape (allocated on first use)
     std::vector<double> tab_h;        // [3][2][6][kMaxLayers], fp64 master copy
     std::vector<T> wf;
     int chunk = 8, remap = 1, wpb = 4;
@@ -408,6 +441,43 @@ struct Engine3 : fdtd3d_engine {
         return FDTD_OK;
     }
 
+    // ---- observables ---------------------------------------------------------------------
+    size_t obs_cells() const { return (size_t)d.Nx * d.Ny * nzl; }
+    int observe_accumulate(double weight, int reset, hipStream_t s) override {
+        int rc;
+        if (!obs_acc && (rc = dalloc((void**)&obs_acc, obs_cells() * sizeof(T)))) return rc;
+        K3<T> a = args();
+        if (full) hipLaunchKernelGGL((k3_observe<T, false, 0>), dim3(4096), dim3(256), 0, s, a, obs_acc, (T*)nullptr, (T)weight, reset, nzl);
+        else hipLaunchKernelGGL((k3_observe<T, true, 0>), dim3(4096), dim3(256), 0, s, a, obs_acc, (T*)nullptr, (T)weight, reset, nzl);
+        FDTD_HIP(hipGetLastError());
+        return FDTD_OK;
+    }
+    // scatter an [owned layers][Ny][Nx] device array into the global [Nz][Ny][Nx] host array
+    int obs_download(const T* dev, double* host, bool take_sqrt) {
+        std::vector<T> st(obs_cells());
+        FDTD_HIP(hipDeviceSynchronize());
+        FDTD_HIP(hipMemcpy(st.data(), dev, st.size() * sizeof(T), hipMemcpyDeviceToHost));
+        double* dst = host + (size_t)d.z_lo * d.Ny * d.Nx;
+        for (size_t q = 0; q < st.size(); ++q) dst[q] = take_sqrt ? std::sqrt((double)st[q]) : (double)st[q];
+        return FDTD_OK;
+    }
+    int observe_rms(double* host, size_t n) override {
+        if (n != (size_t)d.Nx * d.Ny * d.Nz || !host) return fail(FDTD_ERR_ARG, "observe_rms: expected %zu values", (size_t)d.Nx * d.Ny * d.Nz);
+        if (!obs_acc) return fail(FDTD_ERR_STATE, "observe_rms: nothing accumulated yet");
+        return obs_download(obs_acc, host, true);
+    }
+    int observe_frame(double* ex_center, double* e_mag, size_t n, hipStream_t s) override {
+        if (n != (size_t)d.Nx * d.Ny * d.Nz || !ex_center || !e_mag) return fail(FDTD_ERR_ARG, "observe_frame: expected %zu values per array", (size_t)d.Nx * d.Ny * d.Nz);
+        int rc;
+        if (!obs_tmp && (rc = dalloc((void**)&obs_tmp, 2 * obs_cells() * sizeof(T)))) return rc;
+        K3<T> a = args();
+        if (full) hipLaunchKernelGGL((k3_observe<T, false, 1>), dim3(4096), dim3(256), 0, s, a, obs_tmp, obs_tmp + obs_cells(), (T)0, 0, nzl);
+        else hipLaunchKernelGGL((k3_observe<T, true, 1>), dim3(4096), dim3(256), 0, s, a, obs_tmp, obs_tmp + obs_cells(), (T)0, 0, nzl);
+        FDTD_HIP(hipGetLastError());
+        if ((rc = obs_download(obs_tmp, ex_center, false))) return rc;
+        return obs_download(obs_tmp + obs_cells(), e_mag, true);
+    }
+
     // ---- launches -----------------------------------------------------------------------
     K3<T> args() {
         K3<T> a;
@@ -570,6 +640,9 @@ int fdtd3d_sumsq(fdtd3d_handle h, int id, double* out, void* stream) { return h 
 int fdtd3d_checksum(fdtd3d_handle h, int id, uint64_t* out, void* stream) { return h ? h->reduce(id, nullptr, out, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
 size_t fdtd3d_device_bytes(fdtd3d_handle h) { return h ? h->device_bytes() : 0; }
 int fdtd3d_tune(fdtd3d_handle h, int chunk, int remap, int rows) { return h ? h->tune(chunk, remap, rows) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_observe_accumulate(fdtd3d_handle h, double weight, int reset, void* stream) { return h ? h->observe_accumulate(weight, reset, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_observe_rms(fdtd3d_handle h, double* host, size_t n) { return h ? h->observe_rms(host, n) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_observe_frame(fdtd3d_handle h, double* ex_center, double* e_mag, size_t n, void* stream) { return h ? h->observe_frame(ex_center, e_mag, n, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
 int fdtd3d_kernel_timing(fdtd3d_handle h, int enable) {
     if (!h) return fail(FDTD_ERR_ARG, "null handle");
     h->timer.enabled = enable != 0;

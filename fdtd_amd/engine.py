@@ -167,6 +167,21 @@ class Engine3D(_Common):
         _check(lib().fdtd3d_halo(self.h, C.c_int(which), C.c_int(comp), C.byref(p), C.byref(n)), "fdtd3d_halo")
         return p.value, n.value
 
+    def observe_accumulate(self, weight: float, reset: bool, stream=None) -> None:
+        _check(lib().fdtd3d_observe_accumulate(self.h, C.c_double(weight), C.c_int(int(reset)), _stream_handle(stream)), "fdtd3d_observe_accumulate")
+
+    def observe_rms(self, out=None) -> np.ndarray:
+        n = self.N[0] * self.N[1] * self.N[2]
+        out = np.zeros(n) if out is None else out
+        _check(lib().fdtd3d_observe_rms(self.h, out.ctypes.data_as(_dp), C.c_size_t(n)), "fdtd3d_observe_rms")
+        return out
+
+    def observe_frame(self, stream=None):
+        n = self.N[0] * self.N[1] * self.N[2]
+        a, b = np.zeros(n), np.zeros(n)
+        _check(lib().fdtd3d_observe_frame(self.h, a.ctypes.data_as(_dp), b.ctypes.data_as(_dp), C.c_size_t(n), _stream_handle(stream)), "fdtd3d_observe_frame")
+        return a, b
+
     def tune(self, chunk: int = 0, remap: int = -1, rows: int = 0) -> None:
         _check(lib().fdtd3d_tune(self.h, C.c_int(chunk), C.c_int(remap), C.c_int(rows)), "fdtd3d_tune")
 
@@ -187,6 +202,14 @@ class Engine2D(_Common):
         self.desc = desc
         self.h = C.c_void_p()
         _check(lib().fdtd2d_create(C.byref(desc), C.byref(self.h)), "fdtd2d_create")
+
+    def observe_accumulate(self, weight: float, reset: bool, stream=None) -> None:
+        _check(lib().fdtd2d_observe_accumulate(self.h, C.c_double(weight), C.c_int(int(reset)), _stream_handle(stream)), "fdtd2d_observe_accumulate")
+
+    def observe_rms(self) -> np.ndarray:
+        out = np.zeros(self.Nx * self.Nz)
+        _check(lib().fdtd2d_observe_rms(self.h, out.ctypes.data_as(_dp), C.c_size_t(out.size)), "fdtd2d_observe_rms")
+        return out
 
     def step(self, n0: int, count: int = 1, stream=None) -> None:
         _check(lib().fdtd2d_step(self.h, C.c_int(n0), C.c_int(count), _stream_handle(stream)), "fdtd2d_step")

@@ -140,6 +140,18 @@ int fdtd3d_sumsq(fdtd3d_handle h, int id, double* out, void* stream);
  * bit-exact comparisons at sizes too large to download. */
 int fdtd3d_checksum(fdtd3d_handle h, int id, uint64_t* out, void* stream);
 
+/* Cell-centre observables, computed on the device so that the host loop of FDTD3D::run()
+ * (FDTD3D.cpp:1068-1108) never downloads the fields.  Arrays are [Nz][Ny][Nx] with x fastest, the
+ * order run()/dumpFrame() hand to the VTI writer (FDTD3D.cpp:1028-1030); a slab engine fills the
+ * layers it owns.
+ *   accumulate: acc(cell) (+)= (1/16)(sum4 Ex)^2+... * weight, acc zeroed first if reset != 0
+ *               (FDTD3D.cpp:1074-1097; the reference passes weight = 4.0 / n_T0)
+ *   rms:        host = sqrt(acc)                                        (FDTD3D.cpp:1099-1100)
+ *   frame:      ex_center = (1/4) sum4 Ex, e_mag = sqrt(ax^2+ay^2+az^2) (FDTD3D.cpp:1035-1051) */
+int fdtd3d_observe_accumulate(fdtd3d_handle h, double weight, int reset, void* stream);
+int fdtd3d_observe_rms(fdtd3d_handle h, double* host, size_t n);
+int fdtd3d_observe_frame(fdtd3d_handle h, double* ex_center, double* e_mag, size_t n, void* stream);
+
 /* Bytes of device memory held by the handle. */
 size_t fdtd3d_device_bytes(fdtd3d_handle h);
 
@@ -199,6 +211,10 @@ int fdtd2d_get_array(fdtd2d_handle h, int id, double* host, size_t n);
 /* Advance `count` steps n0.. (FDTD2D::stepOnce).  Asynchronous on `stream`. */
 int fdtd2d_step(fdtd2d_handle h, int n0, int count, void* stream);
 int fdtd2d_sumsq(fdtd2d_handle h, int id, double* out, void* stream);
+/* RMS window of Ey on the device (FDTD2D::run, FDTD2D.cpp:515-522): acc(i,k) (+)= Ey^2 * weight for
+ * i < Nx, k < Nz; rms writes sqrt(acc) as [Nx][Nz] with k fastest, the order of the CSV writer. */
+int fdtd2d_observe_accumulate(fdtd2d_handle h, double weight, int reset, void* stream);
+int fdtd2d_observe_rms(fdtd2d_handle h, double* host, size_t n);
 size_t fdtd2d_device_bytes(fdtd2d_handle h);
 int fdtd2d_kernel_timing(fdtd2d_handle h, int enable);
 int fdtd2d_kernel_time(fdtd2d_handle h, int kind, int* launches, double* total_ms);

@@ -192,6 +192,20 @@ class Twin3D(_Base):
     def half_h(self):
         self._f("half_h", None)(self.h)
 
+    def observe_accumulate(self, weight, reset):
+        self._f("observe_accumulate", None)(self.h, C.c_double(weight), C.c_int(int(reset)))
+
+    def observe_rms(self):
+        out = np.zeros(self.N[0] * self.N[1] * self.N[2])
+        self._f("observe_rms", None)(self.h, _ptr(out))
+        return out
+
+    def observe_frame(self):
+        n = self.N[0] * self.N[1] * self.N[2]
+        a, b = np.zeros(n), np.zeros(n)
+        self._f("observe_frame", None)(self.h, _ptr(a), _ptr(b))
+        return a, b
+
     def fill_materials(self, seed, eps_lo, eps_hi, mu_lo, mu_hi):
         self._f("fill_materials", None)(self.h, C.c_uint64(seed), C.c_double(eps_lo), C.c_double(eps_hi),
                                         C.c_double(mu_lo), C.c_double(mu_hi))
@@ -208,6 +222,14 @@ class Twin2D(_Base):
                                C.c_int(iJ), C.c_int(kJ), C.c_int(n_wf)))
         if not self.h:
             raise ValueError("twin2d_create rejected the arguments")
+
+    def observe_accumulate(self, weight, reset):
+        self._f("observe_accumulate", None)(self.h, C.c_double(weight), C.c_int(int(reset)))
+
+    def observe_rms(self):
+        out = np.zeros(self.Nx * self.Nz)
+        self._f("observe_rms", None)(self.h, _ptr(out))
+        return out
 
 
 def cpml_face(n, side, d_step, d_den, dt) -> np.ndarray:
@@ -289,6 +311,11 @@ class Ref3D(_Base):
         return dict(dx=d[0], dy=d[1], dz=d[2], dt=d[3], mu0=d[4], eps0=d[5], c0=d[6], Z0=d[7],
                     Nx=i[0], Ny=i[1], Nz=i[2], steps=i[3], k_Jx=i[4])
 
+    def run(self) -> str:
+        """Run the reference's own time loop; returns the directory holding its output files."""
+        self._f("run", None)(self.h)
+        return os.path.join(_scratch(), "output_3d")
+
     def set_kjx(self, k):
         self._f("set_kjx", None)(self.h, C.c_int(k))
 
@@ -322,6 +349,10 @@ class Ref2D(_Base):
         self._f("scalars", None)(self.h, d, i)
         return dict(dx=d[0], dz=d[1], dt=d[2], mu0=d[3], eps0=d[4], c0=d[5],
                     Nx=i[0], Nz=i[1], steps=i[2], i_Jy=i[3], k_Jy=i[4])
+
+    def run(self) -> str:
+        self._f("run", None)(self.h)
+        return os.path.join(_scratch(), "output_2d")
 
     def set_source_cell(self, i, k):
         self._f("set_source_cell", None)(self.h, C.c_int(i), C.c_int(k))

@@ -157,6 +157,9 @@ int ref2d_set(void* h, int id, const double* src, size_t n) {
     }
     return 1;
 }
+// The reference's whole time loop with RMS window and CSV output (FDTD2D.cpp:501-535); files land
+// in <scratch_dir>/output_2d.
+void ref2d_run(void* h) { ((FDTD2D*)h)->run(); }
 void ref2d_step(void* h, int n0, int count) {
     FDTD2D* s = (FDTD2D*)h;
     for (int n = n0; n < n0 + count; ++n) s->stepOnce(n);       // FDTD2D.cpp:512

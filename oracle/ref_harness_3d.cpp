@@ -219,6 +219,9 @@ void ref3d_step(void* h, int n0, int count) {
     FDTD3D* s = ((Ref3*)h)->s;
     for (int n = n0; n < n0 + count; ++n) { s->updateE(n); s->updateH(); }     // FDTD3D.cpp:1085-1086
 }
+// The reference's whole time loop with its RMS window and file output (FDTD3D.cpp:1062-1111);
+// files land in <scratch_dir>/output_3d.
+void ref3d_run(void* h) { ((Ref3*)h)->s->run(); }
 void ref3d_half_e(void* h, int n) { ((Ref3*)h)->s->updateE(n); }
 void ref3d_half_h(void* h) { ((Ref3*)h)->s->updateH(); }
 

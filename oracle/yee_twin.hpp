@@ -252,6 +252,38 @@ struct Twin3D {
     }
     void step(int n) { half_e(n); half_h(); }
 
+    // Cell-centre observables of FDTD3D::run / dumpFrame (FDTD3D.cpp:1023-1097); arrays [Nz][Ny][Nx],
+    // x fastest.  Sums run in the reference's order; the square root is taken in double.
+    std::vector<T> acc;
+    void edge_sums(int i, int j, int k, T& sx, T& sy, T& sz) const {
+        const Box3 bx = boxE(0, N), by = boxE(1, N), bz = boxE(2, N);
+        sx = E[0][bx.at(i, j, k)] + E[0][bx.at(i, j + 1, k)] + E[0][bx.at(i, j, k + 1)] + E[0][bx.at(i, j + 1, k + 1)];
+        sy = E[1][by.at(i, j, k)] + E[1][by.at(i + 1, j, k)] + E[1][by.at(i, j, k + 1)] + E[1][by.at(i + 1, j, k + 1)];
+        sz = E[2][bz.at(i, j, k)] + E[2][bz.at(i + 1, j, k)] + E[2][bz.at(i, j + 1, k)] + E[2][bz.at(i + 1, j + 1, k)];
+    }
+    void observe_accumulate(double weight, bool reset) {
+        acc.resize((size_t)N[0] * N[1] * N[2], 0);
+        if (reset) std::fill(acc.begin(), acc.end(), (T)0);
+        for (int k = 0; k < N[2]; ++k) for (int j = 0; j < N[1]; ++j) for (int i = 0; i < N[0]; ++i) {
+            T sx, sy, sz;
+            edge_sums(i, j, k, sx, sy, sz);
+            const T e_sq = (T)0.0625 * (sx * sx + sy * sy + sz * sz);
+            T& a = acc[((size_t)k * N[1] + j) * N[0] + i];
+            a = a + e_sq * (T)weight;
+        }
+    }
+    void observe_rms(double* out) const { for (size_t q = 0; q < acc.size(); ++q) out[q] = std::sqrt((double)acc[q]); }
+    void observe_frame(double* ex_center, double* e_mag) const {
+        for (int k = 0; k < N[2]; ++k) for (int j = 0; j < N[1]; ++j) for (int i = 0; i < N[0]; ++i) {
+            T sx, sy, sz;
+            edge_sums(i, j, k, sx, sy, sz);
+            const T ax = (T)0.25 * sx, ay = (T)0.25 * sy, az = (T)0.25 * sz;
+            const size_t q = ((size_t)k * N[1] + j) * N[0] + i;
+            ex_center[q] = (double)ax;
+            e_mag[q] = std::sqrt((double)(T)(ax * ax + ay * ay + az * az));
+        }
+    }
+
     // eps_c = lo + (hi-lo)*u(seed, c, canonical index); mu likewise with stream 3+c.
     void fill_materials(uint64_t seed, double eps_lo, double eps_hi, double mu_lo, double mu_hi) {
         for (int c = 0; c < 3; ++c) {
@@ -376,6 +408,19 @@ struct Twin2D {
         F2[f].swap(F1[f]); F1[f] = F[f];
         S2[f].swap(S1[f]); S1[f] = S[f];
     }
+
+    // RMS window of Ey (FDTD2D.cpp:515-522), [Nx][Nz] with k fastest
+    std::vector<T> acc;
+    void observe_accumulate(double weight, bool reset) {
+        acc.resize((size_t)Nx * Nz, 0);
+        if (reset) std::fill(acc.begin(), acc.end(), (T)0);
+        for (int i = 0; i < Nx; ++i) for (int k = 0; k < Nz; ++k) {
+            const T e = F[0][idE(i, k)];
+            T& a = acc[(size_t)i * Nz + k];
+            a = a + e * e * (T)weight;
+        }
+    }
+    void observe_rms(double* out) const { for (size_t q = 0; q < acc.size(); ++q) out[q] = std::sqrt((double)acc[q]); }
 
     void step(int n) {
         T dummy = 0;

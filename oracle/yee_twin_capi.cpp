@@ -128,6 +128,10 @@ void twin3d_fill_materials(void* h, uint64_t seed, double eps_lo, double eps_hi,
     else p->d.fill_materials(seed, eps_lo, eps_hi, mu_lo, mu_hi);
 }
 
+void twin3d_observe_accumulate(void* h, double weight, int reset) { auto* p = (Any3D*)h; if (p->prec == 32) p->f.observe_accumulate(weight, reset != 0); else p->d.observe_accumulate(weight, reset != 0); }
+void twin3d_observe_rms(void* h, double* out) { auto* p = (Any3D*)h; if (p->prec == 32) p->f.observe_rms(out); else p->d.observe_rms(out); }
+void twin3d_observe_frame(void* h, double* ex_center, double* e_mag) { auto* p = (Any3D*)h; if (p->prec == 32) p->f.observe_frame(ex_center, e_mag); else p->d.observe_frame(ex_center, e_mag); }
+
 // fp64 setup generators (outputs sized by the caller).
 void twin_consts(double out[4]) { Consts K; out[0] = K.c0; out[1] = K.mu0; out[2] = K.eps0; out[3] = K.Z0; }
 void twin_cpml_face(int n, int side, double d_step, double d_den, double dt, double out[/*6*n*/]) {
@@ -186,6 +190,8 @@ int twin2d_get(void* h, int id, double* dst, size_t n) {
     auto* p = (Any2D*)h;
     return p->prec == 32 ? take(find2(p->f, id), dst, n) : take(find2(p->d, id), dst, n);
 }
+void twin2d_observe_accumulate(void* h, double weight, int reset) { auto* p = (Any2D*)h; if (p->prec == 32) p->f.observe_accumulate(weight, reset != 0); else p->d.observe_accumulate(weight, reset != 0); }
+void twin2d_observe_rms(void* h, double* out) { auto* p = (Any2D*)h; if (p->prec == 32) p->f.observe_rms(out); else p->d.observe_rms(out); }
 void twin2d_step(void* h, int n0, int count) {
     auto* p = (Any2D*)h;
     for (int n = n0; n < n0 + count; ++n) { if (p->prec == 32) p->f.step(n); else p->d.step(n); }

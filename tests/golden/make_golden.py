@@ -174,6 +174,41 @@ def g5():
     save("g5_2d_pec512", meta, ins, outs, {"probe": probe})
 
 
+def _pack_dir(src, dst):
+    import gzip
+    os.makedirs(dst, exist_ok=True)
+    for f in os.listdir(dst):
+        os.remove(os.path.join(dst, f))
+    for f in sorted(os.listdir(src)):
+        with open(os.path.join(src, f), "rb") as fi, gzip.GzipFile(os.path.join(dst, f + ".gz"), "wb", mtime=0) as fo:
+            fo.write(fi.read())
+    print(dst, sorted(os.listdir(dst)))
+
+
+def g7():
+    """Output files of the reference's own run() on a small 3-D grid (VTI, ASCII)."""
+    N, npml, steps = (16, 14, 24), (3,) * 6, 41
+    r = po.Ref3D(N, npml, steps)
+    s = r.scalars()
+    out = r.run()
+    _pack_dir(out, os.path.join(OUT, "run3d"))
+    with open(os.path.join(OUT, "run3d", "meta.json"), "w") as f:
+        json.dump(dict(N=N, npml=npml, steps=steps, k_Jx=s["k_Jx"], note="reference run(): default source and materials, "
+                       "frames every 20 steps, RMS window of 20 steps; files gzip-compressed verbatim"), f, indent=1)
+
+
+def g8():
+    """Output files of the reference's own run() on a small 2-D grid (CSV)."""
+    Nx, Nz, npml, steps = 48, 40, (5,) * 4, 81
+    r = po.Ref2D(Nx, Nz, npml, steps)
+    r.set_source_cell(12, 20)
+    out = r.run()
+    _pack_dir(out, os.path.join(OUT, "run2d"))
+    with open(os.path.join(OUT, "run2d", "meta.json"), "w") as f:
+        json.dump(dict(Nx=Nx, Nz=Nz, npml=npml, steps=steps, i_Jy=12, k_Jy=20, note="reference run(): default Lorentz slab and "
+                       "source waveform, frames every 20 steps + final, RMS window of 40 steps; files gzip-compressed verbatim"), f, indent=1)
+
+
 def g6():
     r2 = po.Ref2D()
     r2.step(0, 200)
@@ -189,6 +224,6 @@ def g6():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for w in which:
         globals()[w]()

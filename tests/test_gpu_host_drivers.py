@@ -1,0 +1,112 @@
+"""The C++ host drivers (CMake targets fdtd3d / fdtd2d) end to end on the GPU: with fp64 arithmetic
+their output files must equal, byte for byte, the files the reference's own run() wrote for the
+same small problems (tests/golden/run3d, run2d: device observables + writers + output cadence)."""
+import gzip
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import fdtd_amd
+from oracle import pyoracle as po
+from tests import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(binary, env, cwd):
+    exe = os.path.join(ROOT, binary, "build", binary)
+    if not os.path.exists(exe):
+        pytest.fail(f"{exe} missing: run __graft_entry__.build()")
+    e = dict(os.environ)
+    e.update({k: str(v) for k, v in env.items()})
+    r = subprocess.run([exe], cwd=cwd, env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout[-2000:]
+    return r.stdout
+
+
+def _compare_dir(got_dir, fixture_dir):
+    names = sorted(f[:-3] for f in os.listdir(fixture_dir) if f.endswith(".gz"))
+    assert sorted(os.listdir(got_dir)) == names
+    for n in names:
+        want = gzip.open(os.path.join(fixture_dir, n + ".gz"), "rb").read()
+        got = open(os.path.join(got_dir, n), "rb").read()
+        assert got == want, f"{n}: differs from the reference's file"
+    return names
+
+
+def test_fdtd3d_driver_writes_the_reference_files(tmp_path):
+    fx = os.path.join(util.GOLDEN, "run3d")
+    meta = json.load(open(os.path.join(fx, "meta.json")))
+    out = _run("fdtd3d", dict(FDTD3D_NX=meta["N"][0], FDTD3D_NY=meta["N"][1], FDTD3D_NZ=meta["N"][2], FDTD3D_NPML=meta["npml"][0],
+                              FDTD3D_STEPS=meta["steps"], FDTD3D_PRECISION=64), str(tmp_path))
+    assert "[grid] Nx=16, Ny=14, Nz=24" in out and "[n=40] frame dumped." in out and "Done. VTI in ./output_3d" in out
+    names = _compare_dir(str(tmp_path / "output_3d"), fx)
+    assert "E_mag_rms_t00040.vti" in names and "Ex_t00020.vti" in names
+
+
+def test_fdtd3d_driver_full_storage_and_fp32(tmp_path):
+    fx = os.path.join(util.GOLDEN, "run3d")
+    meta = json.load(open(os.path.join(fx, "meta.json")))
+    env = dict(FDTD3D_NX=meta["N"][0], FDTD3D_NY=meta["N"][1], FDTD3D_NZ=meta["N"][2], FDTD3D_NPML=meta["npml"][0], FDTD3D_STEPS=meta["steps"])
+    _run("fdtd3d", dict(env, FDTD3D_PRECISION=64, FDTD3D_LEAN=0), str(tmp_path))
+    _compare_dir(str(tmp_path / "output_3d"), fx)
+    _run("fdtd3d", dict(env, FDTD3D_PRECISION=32), str(tmp_path))
+    # fp32: same files, values within the stated drift (relative L2 <= 1e-6 of the field's norm)
+    def values(path, opener):
+        txt = opener(path).read().decode()
+        body = txt.split('NumberOfComponents="1">\n')[1].split("        </DataArray>")[0]
+        return np.array(body.split(), dtype=np.float64)
+    for n in ("Ex_t00040.vti", "E_mag_rms_t00040.vti"):
+        got = values(str(tmp_path / "output_3d" / n), lambda p: open(p, "rb"))
+        want = values(os.path.join(fx, n + ".gz"), lambda p: gzip.open(p, "rb"))
+        assert util.rel_l2(got, want) < 1e-6
+
+
+def test_fdtd2d_driver_writes_the_reference_files(tmp_path):
+    fx = os.path.join(util.GOLDEN, "run2d")
+    meta = json.load(open(os.path.join(fx, "meta.json")))
+    out = _run("fdtd2d", dict(FDTD2D_NX=meta["Nx"], FDTD2D_NZ=meta["Nz"], FDTD2D_NPML=meta["npml"][0], FDTD2D_STEPS=meta["steps"],
+                              FDTD2D_IJY=meta["i_Jy"], FDTD2D_KJY=meta["k_Jy"], FDTD2D_PRECISION=64), str(tmp_path))
+    assert "Done. CSV in ./output_2d" in out
+    names = _compare_dir(str(tmp_path / "output_2d"), fx)
+    assert "dims.txt" in names and "eymag_t00080.csv" in names and "ey_t00081.csv" in names
+
+
+@pytest.mark.parametrize("prec,mode", [(32, 0), (32, 1), (64, 1)])
+def test_device_observables_equal_twin(prec, mode):
+    meta, ins, _, _ = util.load_fixture("g3_3d_hetero")
+    eng = fdtd_amd.Engine3D(meta["N"], meta["npml"], (meta["dx"], meta["dy"], meta["dz"]), meta["dt"], meta["mu0"], meta["k_Jx"],
+                            meta["steps"], precision=prec, mode=mode)
+    tw = util.twin3d_from_meta(meta, prec)
+    util.feed(eng, ins)
+    util.feed(tw, ins)
+    for n in range(12):
+        eng.step(n, 1)
+        tw.step(n, 1)
+        eng.observe_accumulate(0.1, n % 5 == 0)
+        tw.observe_accumulate(0.1, n % 5 == 0)
+    util.assert_equal_arrays(eng.observe_rms(), tw.observe_rms(), "RMS window")
+    a, b = eng.observe_frame()
+    ta, tb = tw.observe_frame()
+    util.assert_equal_arrays(a, ta, "centred Ex")
+    util.assert_equal_arrays(b, tb, "|E|")
+    assert np.abs(a).max() > 0
+
+
+def test_device_observables_2d_equal_twin():
+    meta, ins, _, _ = util.load_fixture("g4_2d_slab")
+    eng = fdtd_amd.Engine2D(meta["Nx"], meta["Nz"], meta["npml"], meta["dx"], meta["dz"], meta["dt"], meta["mu0"], meta["eps0"],
+                            meta["i_Jy"], meta["k_Jy"], meta["steps"], precision=32)
+    tw = util.twin2d_from_meta(meta, 32)
+    util.feed(eng, ins)
+    util.feed(tw, ins)
+    for n in range(30):
+        eng.step(n, 1)
+        tw.step(n, 1)
+        eng.observe_accumulate(0.05, n % 10 == 0)
+        tw.observe_accumulate(0.05, n % 10 == 0)
+    util.assert_equal_arrays(eng.observe_rms(), tw.observe_rms(), "2-D RMS window")
