@@ -159,6 +159,17 @@ def main():
     finite = all(v == v and v < float("inf") for v in sums)
     ex_energy = sums[0]
 
+    # HBM-side bytes per launch from the PMC passes recorded under profiles/ (the counters cannot be
+    # read from inside this process); only reported when this run is the configuration they were taken on
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_traffic_1024_lean.json")) as f:
+            rec = json.load(f)
+        if lean and has_mu and n_edge == 1024 and cells_local == 1024 ** 3:
+            traffic = rec["per_launch"][dom]["total_bytes"]
+    except (OSError, KeyError, ValueError):
+        traffic = None
+
     if rank == 0:
         total_cells = Nx * Ny * Nz
         value = total_cells * args.steps / el / 1e6
@@ -172,7 +183,8 @@ def main():
                        "grid": [Nx, Ny, Nz], "cpml_layers": 20, "mu_grid": has_mu, "decomposition": f"z-slabs x{world}",
                        "storage": "D,B resident; E=D/eps, H=B/mu recomputed in the consuming kernel" if lean else "D,E,B,H resident", "device_bytes_per_gpu": eng.device_bytes()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": cells_local * (bytes_e if dom == "k3_half_e" else bytes_h),
                          "algorithmic_bytes_per_cell": bytes_e if dom == "k3_half_e" else bytes_h,
                          "cells_per_launch": cells_local,
                          "ms_per_step_e_half": t_e * 1e3, "ms_per_step_h_half": t_h * 1e3,

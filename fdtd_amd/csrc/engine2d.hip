@@ -25,6 +25,20 @@ __global__ void k2_sumsq(const T* arr, int Nx, int px, int rows, double* partial
     for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
 }
+// flags[k][tile] = 1 if any of C1, C2, C3 is non-zero (or NaN) in the 64-lane tile of row k
+template <typename T, int V>
+__global__ void k2_flags(const T* c1, const T* c2, const T* c3, unsigned char* flags, int px, int rows, int ntx) {
+    const int lane = threadIdx.x & 63;
+    const size_t tile = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tile >= (size_t)rows * ntx) return;
+    const int k = (int)(tile / ntx), tx = (int)(tile % ntx);
+    const size_t idx = (size_t)k * px + ((size_t)tx * 64 + lane) * V;
+    bool any = false;
+    for (int e = 0; e < V; ++e) any = any || !(c1[idx + e] == (T)0) || !(c2[idx + e] == (T)0) || !(c3[idx + e] == (T)0);
+    const unsigned long long m = __ballot(any);
+    if (lane == 0) flags[tile] = m != 0ull;
+}
+
 // acc(k,i) (+)= Ey(i,k)^2 * weight, device layout [k][px]
 template <typename T>
 __global__ void k2_observe(const T* ey, T* acc, int Nx, int Nz, int px, T weight, int reset) {
@@ -65,6 +79,7 @@ struct Engine2 : fdtd2d_engine {
     T* ph_z[2][2];      // [0 = ey, 1 = mx][side]   layout [l][px]
     T* ph_x[2][2];      // [0 = ey, 1 = mz][side]   layout [k][strip]
     T* tab_d = nullptr; T* xrow_d = nullptr; double* red_d = nullptr;
+    unsigned char* disp_d = nullptr;
     std::vector<double> tab_h;
     std::vector<T> Jy;
     int chunk = 32, remap = 1;
@@ -107,6 +122,7 @@ struct Engine2 : fdtd2d_engine {
         if ((rc = dalloc((void**)&tab_d, tab_h.size() * sizeof(T)))) return rc;
         if ((rc = dalloc((void**)&xrow_d, (size_t)6 * px * sizeof(T)))) return rc;
         if ((rc = dalloc((void**)&red_d, 1024 * sizeof(double)))) return rc;
+        if ((rc = dalloc((void**)&disp_d, (size_t)nz1 * (px / (kLanes * V)) + 64))) return rc;
         Jy.assign(d.n_wf > 0 ? d.n_wf : 0, (T)0);
         return FDTD_OK;
     }
@@ -205,6 +221,13 @@ struct Engine2 : fdtd2d_engine {
             if (off >= 0) st[(size_t)off] = (T)host[o];
         }
         FDTD_HIP(hipMemcpy(m.dev, st.data(), st.size() * sizeof(T), hipMemcpyHostToDevice));
+        if (id >= FDTD2D_C1 && id <= FDTD2D_C3) {
+            const int ntx = px / (kLanes * V);
+            const size_t tiles = (size_t)nz1 * ntx;
+            hipLaunchKernelGGL((k2_flags<T, V>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, 0, C[0], C[1], C[2], disp_d, px, nz1, ntx);
+            FDTD_HIP(hipGetLastError());
+            FDTD_HIP(hipDeviceSynchronize());
+        }
         return FDTD_OK;
     }
     int get_array(int id, double* host, size_t n) override {
@@ -244,7 +267,7 @@ struct Engine2 : fdtd2d_engine {
         for (int f = 0; f < 3; ++f) { a.F1[f] = Fa[f]; a.F2[f] = Fb[f]; a.S1[f] = Sa[f]; a.S2[f] = Sb[f]; }
         a.C1 = C[0]; a.C2 = C[1]; a.C3 = C[2];
         for (int s = 0; s < 2; ++s) { a.ph_ey_z[s] = ph_z[0][s]; a.ph_mx_z[s] = ph_z[1][s]; a.ph_ey_x[s] = ph_x[0][s]; a.ph_mz_x[s] = ph_x[1][s]; }
-        a.tab = tab_d; a.xrow = xrow_d;
+        a.tab = tab_d; a.xrow = xrow_d; a.disp = disp_d;
         a.Nx = d.Nx; a.Nz = d.Nz; a.px = px; a.nz1 = nz1;
         for (int ax = 0; ax < 2; ++ax) for (int s = 0; s < 2; ++s) a.np[ax][s] = np[ax][s];
         a.xwn = xwn; a.xwp = xwp; a.xp0 = xp0;

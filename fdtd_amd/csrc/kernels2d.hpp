@@ -7,6 +7,11 @@
 // history buffers of a field ping-pong: the new sample overwrites the n-2 sample of the same
 // cell (the recursion is point-wise) and the host swaps the two pointers after the launch.
 //
+// Tiles (64 lanes of one row) in which C1 = C2 = C3 = 0 take a short cut: there the recursion is
+// exactly f = drive / 1 with S = 0 (every product with a zero coefficient is a zero), so only the
+// new sample is written and no history is read.  The per-tile flags are rebuilt on the device
+// whenever a coefficient array is uploaded.
+//
 // Device layout: [row k][i], i unit-stride, rows padded to a multiple of 256 elements, Nz+1
 // rows; the wall column i = Nx of Ey and Hx is never written by the reference and not stored.
 // A wave owns 64 lanes x 16 bytes of one row and marches through a chunk of rows, carrying
@@ -33,6 +38,7 @@ struct K2 {
     T dt, dtd[2], mu0, eps0;
     int chunk, nbx, nbz, ntx;      // rows per wave, workgroups along x and z, x tiles in total
     int remap;
+    const unsigned char* disp;     // [nz1][ntx]: 1 where the 64-lane tile of that row holds a dispersive cell
 };
 
 // Second-order Lorentz recursion of one sample (FDTD2D.cpp:369-373):
@@ -47,7 +53,7 @@ __device__ __forceinline__ void lorentz(T drive, T c1, T c2, T c3, T f1, T f2, T
 
 template <typename T>
 struct Tile2 {
-    int lane, i0, kb, ke;
+    int lane, i0, kb, ke, tx;
     bool ok;
     unsigned m_lt, m_in;
     bool lane_n, lane_p;
@@ -62,6 +68,7 @@ __device__ __forceinline__ Tile2<T> decode_tile2(const K2<T>& a) {
     const int bx = bid % a.nbx, bz = bid / a.nbx;
     const int tx = bx * kWavesPerBlock + w;
     t.ok = tx < a.ntx;
+    t.tx = tx;
     t.i0 = (tx * kLanes + t.lane) * V;
     t.kb = bz * a.chunk;
     t.ke = min(t.kb + a.chunk, a.nz1);
@@ -109,19 +116,28 @@ __global__ void __launch_bounds__(256) k2_part_e(const K2<T> a) {
         }
         stv<T, V>(a.Dy + idx, d);
         if (row_lt) {                                                                      // :365-379
-            const size_t ic = idx;   // C arrays share the padded layout
-            const P c1 = ldv<T, V>(a.C1 + ic), c2 = ldv<T, V>(a.C2 + ic), c3 = ldv<T, V>(a.C3 + ic);
-            const P f1 = ldv<T, V>(a.F1[0] + idx), s1 = ldv<T, V>(a.S1[0] + idx);
-            P f2 = ldv<T, V>(a.F2[0] + idx), s2 = ldv<T, V>(a.S2[0] + idx);
+            // A tile without dispersive cells (C1 = C2 = C3 = 0 throughout) reduces the recursion to
+            // Ey = Dy/eps0 and S = 0: no history is read and the polarisation sums are left alone.
+            const bool dispersive = __builtin_amdgcn_readfirstlane((int)a.disp[(size_t)k * a.ntx + t.tx]) != 0;
+            if (dispersive) {
+                const P c1 = ldv<T, V>(a.C1 + idx), c2 = ldv<T, V>(a.C2 + idx), c3 = ldv<T, V>(a.C3 + idx);
+                const P f1 = ldv<T, V>(a.F1[0] + idx), s1 = ldv<T, V>(a.S1[0] + idx);
+                P f2 = ldv<T, V>(a.F2[0] + idx), s2 = ldv<T, V>(a.S2[0] + idx);
 #pragma unroll
-            for (int e = 0; e < V; ++e)
-                if (t.m_lt & (1u << e)) {
-                    T f, s;
-                    lorentz<T>(d.v[e] / a.eps0, c1.v[e], c2.v[e], c3.v[e], f1.v[e], f2.v[e], s1.v[e], s2.v[e], f, s);
-                    f2.v[e] = f; s2.v[e] = s;
-                }
-            stv<T, V>(a.F2[0] + idx, f2);
-            stv<T, V>(a.S2[0] + idx, s2);
+                for (int e = 0; e < V; ++e)
+                    if (t.m_lt & (1u << e)) {
+                        T f, s;
+                        lorentz<T>(d.v[e] / a.eps0, c1.v[e], c2.v[e], c3.v[e], f1.v[e], f2.v[e], s1.v[e], s2.v[e], f, s);
+                        f2.v[e] = f; s2.v[e] = s;
+                    }
+                stv<T, V>(a.F2[0] + idx, f2);
+                stv<T, V>(a.S2[0] + idx, s2);
+            } else {
+                P f2 = zero_pack<T, V>();
+#pragma unroll
+                for (int e = 0; e < V; ++e) if (t.m_lt & (1u << e)) f2.v[e] = d.v[e] / a.eps0;
+                stv<T, V>(a.F2[0] + idx, f2);
+            }
         }
         hx_km = hx;
     }
@@ -147,24 +163,33 @@ __global__ void __launch_bounds__(256) k2_part_h(const K2<T> a) {
             const int zk = zone_h(k, Nz, a.np[1][0], a.np[1][1], false, lk);
             const bool row_in = k >= 1;
             const T ey_r = right_of<T, V>(ey, Ey + idx, i0, lane, px);
-            const P c1 = ldv<T, V>(a.C1 + idx), c2 = ldv<T, V>(a.C2 + idx), c3 = ldv<T, V>(a.C3 + idx);
+            const bool dispersive = __builtin_amdgcn_readfirstlane((int)a.disp[(size_t)k * a.ntx + t.tx]) != 0;
+            P c1 = zero_pack<T, V>(), c2 = c1, c3 = c1;
+            if (dispersive) { c1 = ldv<T, V>(a.C1 + idx); c2 = ldv<T, V>(a.C2 + idx); c3 = ldv<T, V>(a.C3 + idx); }
             // ---- Bx += dEy/dz on columns 1..Nx-1 (FDTD2D.cpp:383-416), then Hx (:460-468)
             {
                 P b = ldv<T, V>(a.Bx + idx);
                 apply_uniform<+1, T, V>(b, diff<T, V>(ey_kp, ey), t.m_in, zk, lk, face_z, 3, a.dtd[1], a.dt,
                                         a.ph_mx_z[0] + (size_t)lk * px + i0, a.ph_mx_z[1] + (size_t)lk * px + i0);
                 stv<T, V>(a.Bx + idx, b);
-                const P f1 = ldv<T, V>(a.F1[1] + idx), s1 = ldv<T, V>(a.S1[1] + idx);
-                P f2 = ldv<T, V>(a.F2[1] + idx), s2 = ldv<T, V>(a.S2[1] + idx);
+                if (dispersive) {
+                    const P f1 = ldv<T, V>(a.F1[1] + idx), s1 = ldv<T, V>(a.S1[1] + idx);
+                    P f2 = ldv<T, V>(a.F2[1] + idx), s2 = ldv<T, V>(a.S2[1] + idx);
 #pragma unroll
-                for (int e = 0; e < V; ++e)
-                    if (t.m_lt & (1u << e)) {
-                        T f, s;
-                        lorentz<T>(b.v[e] / a.mu0, c1.v[e], c2.v[e], c3.v[e], f1.v[e], f2.v[e], s1.v[e], s2.v[e], f, s);
-                        f2.v[e] = f; s2.v[e] = s;
-                    }
-                stv<T, V>(a.F2[1] + idx, f2);
-                stv<T, V>(a.S2[1] + idx, s2);
+                    for (int e = 0; e < V; ++e)
+                        if (t.m_lt & (1u << e)) {
+                            T f, s;
+                            lorentz<T>(b.v[e] / a.mu0, c1.v[e], c2.v[e], c3.v[e], f1.v[e], f2.v[e], s1.v[e], s2.v[e], f, s);
+                            f2.v[e] = f; s2.v[e] = s;
+                        }
+                    stv<T, V>(a.F2[1] + idx, f2);
+                    stv<T, V>(a.S2[1] + idx, s2);
+                } else {
+                    P f2 = zero_pack<T, V>();
+#pragma unroll
+                    for (int e = 0; e < V; ++e) if (t.m_lt & (1u << e)) f2.v[e] = b.v[e] / a.mu0;
+                    stv<T, V>(a.F2[1] + idx, f2);
+                }
             }
             // ---- Bz -= dEy/dx on rows 1..Nz-1 (FDTD2D.cpp:420-453), then Hz (:470-477)
             {
@@ -173,17 +198,24 @@ __global__ void __launch_bounds__(256) k2_part_h(const K2<T> a) {
                                         a.dtd[0], a.dt, t.lane_n ? a.ph_mz_x[0] + (size_t)k * a.xwn + i0 : nullptr,
                                         t.lane_p ? a.ph_mz_x[1] + (size_t)k * a.xwp + (i0 - a.xp0) : nullptr);
                 stv<T, V>(a.Bz + idx, b);
-                const P f1 = ldv<T, V>(a.F1[2] + idx), s1 = ldv<T, V>(a.S1[2] + idx);
-                P f2 = ldv<T, V>(a.F2[2] + idx), s2 = ldv<T, V>(a.S2[2] + idx);
+                if (dispersive) {
+                    const P f1 = ldv<T, V>(a.F1[2] + idx), s1 = ldv<T, V>(a.S1[2] + idx);
+                    P f2 = ldv<T, V>(a.F2[2] + idx), s2 = ldv<T, V>(a.S2[2] + idx);
 #pragma unroll
-                for (int e = 0; e < V; ++e)
-                    if (t.m_lt & (1u << e)) {
-                        T f, s;
-                        lorentz<T>(b.v[e] / a.mu0, c1.v[e], c2.v[e], c3.v[e], f1.v[e], f2.v[e], s1.v[e], s2.v[e], f, s);
-                        f2.v[e] = f; s2.v[e] = s;
-                    }
-                stv<T, V>(a.F2[2] + idx, f2);
-                stv<T, V>(a.S2[2] + idx, s2);
+                    for (int e = 0; e < V; ++e)
+                        if (t.m_lt & (1u << e)) {
+                            T f, s;
+                            lorentz<T>(b.v[e] / a.mu0, c1.v[e], c2.v[e], c3.v[e], f1.v[e], f2.v[e], s1.v[e], s2.v[e], f, s);
+                            f2.v[e] = f; s2.v[e] = s;
+                        }
+                    stv<T, V>(a.F2[2] + idx, f2);
+                    stv<T, V>(a.S2[2] + idx, s2);
+                } else {
+                    P f2 = zero_pack<T, V>();
+#pragma unroll
+                    for (int e = 0; e < V; ++e) if (t.m_lt & (1u << e)) f2.v[e] = b.v[e] / a.mu0;
+                    stv<T, V>(a.F2[2] + idx, f2);
+                }
             }
         }
         ey = ey_kp;
