@@ -1,5 +1,5 @@
 // engine3d.hip -- host side of the 3-D engine: device state, array exchange, launches, C ABI.
-#include "kernels3d.hpp"
+#include "kernels3d_fused.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -118,6 +118,7 @@ struct fdtd3d_engine {
     virtual int fill_materials(uint64_t seed, double elo, double ehi, double mlo, double mhi) = 0;
     virtual int half_e(int n, int part, hipStream_t s) = 0;
     virtual int half_h(int part, hipStream_t s) = 0;
+    virtual int step(int n, hipStream_t s) = 0;
     virtual int halo(int which, int comp, void** p, size_t* bytes) = 0;
     virtual int reduce(int id, double* sumsq, uint64_t* checksum, hipStream_t s) = 0;
     virtual size_t device_bytes() = 0;
@@ -137,7 +138,11 @@ struct Engine3 : fdtd3d_engine {
     int px = 0, ny1 = 0, nzl = 0, nzp = 0, zoff = 0;
     int np[3][2];
     int xwn = 0, xwp = 0, xp0 = 0;
-    bool last_rank = false, full = true;
+    bool last_rank = false, full = true, fused = false;
+    T* alt[18] = {nullptr};           // fused stepping: the other D and B buffers of the ping-pong
+    T* phE2[3][3][2];
+    int wpbf = 16;                    // fused kernel: waves per workgroup (the last one is a halo row)
+    int fvec = VecWidth<T>::V;        // fused kernel: elements per lane (V or V/2)
     size_t plane = 0, fsize = 0, bytes = 0;
     T* fld[18] = {nullptr};           // D E B H eps mu, three each (mu only if has_mu; E,H absent in LEAN)
     T* phE[3][3][2];
@@ -178,6 +183,7 @@ struct Engine3 : fdtd3d_engine {
         zoff = d.z_lo - 1;
         last_rank = d.z_hi == d.Nz;
         full = d.mode == FDTD3D_MODE_FULL;
+        fused = d.mode == FDTD3D_MODE_FUSED;
         plane = (size_t)ny1 * px;
         fsize = plane * nzp;
         xwn = np[0][0] > 0 ? round_up(np[0][0] + 1, 4) : 0;
@@ -185,6 +191,7 @@ struct Engine3 : fdtd3d_engine {
         xwp = np[0][1] > 0 ? round_up(d.Nx - xp0, 4) : 0;
         if (const char* e = getenv("FDTD_Z_CHUNK")) { int c = atoi(e); if (c >= 1 && c <= 4096) chunk = c; }
         if (const char* e = getenv("FDTD_XCD_REMAP")) remap = atoi(e) != 0;
+        if (const char* e = getenv("FDTD_FUSED_VEC")) { int v = atoi(e); if (v == V || v == V / 2) fvec = v; }
         if (const char* e = getenv("FDTD_ROWS_PER_GROUP")) { int w = atoi(e); if (w >= 1 && w <= 4) wpb = w; }
 
         int rc;
@@ -196,6 +203,7 @@ struct Engine3 : fdtd3d_engine {
             // one row of slack behind every array: vector accesses of the last row may look one pack ahead
             if ((rc = dalloc((void**)&fld[id], (fsize + px) * sizeof(T)))) return rc;
             if (f >= 4) { if ((rc = fill_const(fld[id], fsize + px, (T)1))) return rc; }
+            if (fused && (f == 0 || f == 2)) { if ((rc = dalloc((void**)&alt[id], (fsize + px) * sizeof(T)))) return rc; }
         }
         for (int m = 0; m < 2; ++m) for (int c = 0; c < 3; ++c) for (int a = 0; a < 3; ++a) for (int s = 0; s < 2; ++s) {
             T** slot = m ? &phM[c][a][s] : &phE[c][a][s];
@@ -208,6 +216,7 @@ struct Engine3 : fdtd3d_engine {
             else n = (size_t)nzp * ny1 * (s ? xwp : xwn);
             phSize[m][c][a][s] = n;
             if ((rc = dalloc((void**)slot, (n + px) * sizeof(T)))) return rc;
+            if (!m) { phE2[c][a][s] = nullptr; if (fused && (rc = dalloc((void**)&phE2[c][a][s], (n + px) * sizeof(T)))) return rc; }
         }
         tab_h.assign((size_t)3 * 2 * 6 * kMaxLayers, 0.0);
         if ((rc = dalloc((void**)&tab_d, tab_h.size() * sizeof(T)))) return rc;
@@ -229,6 +238,7 @@ struct Engine3 : fdtd3d_engine {
         if (c >= 1 && c <= 4096) chunk = c;
         if (r == 0 || r == 1) remap = r;
         if (w >= 1 && w <= 4) wpb = w;
+        if (fused && w >= 2 && w <= 16) wpbf = w;
         return FDTD_OK;
     }
 
@@ -236,6 +246,7 @@ struct Engine3 : fdtd3d_engine {
     struct Map {
         int n[3] = {0, 0, 0};     // canonical extents
         T* dev = nullptr;
+        T* dev2 = nullptr;        // second buffer that must receive the same upload (fused ping-pong)
         size_t dev_elems = 0;
         int kind = -1;            // 0 field, 1 phi z, 2 phi y, 3 phi x, 4 mag
         bool mag = false;
@@ -250,7 +261,7 @@ struct Engine3 : fdtd3d_engine {
             if (f == 5 && !d.has_mu) return false;
             const bool electric = (f == 0 || f == 1 || f == 4);
             for (int q = 0; q < 3; ++q) m.n[q] = electric ? N[q] + (q != c) : N[q] + (q == c);
-            m.dev = fld[id]; m.dev_elems = fsize; m.kind = 0; m.c = c;
+            m.dev = fld[id]; m.dev2 = alt[id]; m.dev_elems = fsize; m.kind = 0; m.c = c;
             return true;
         }
         const bool isE = id >= FDTD3D_PHI_E && id < FDTD3D_PHI_E + 18, isM = id >= FDTD3D_PHI_M && id < FDTD3D_PHI_M + 18;
@@ -261,6 +272,7 @@ struct Engine3 : fdtd3d_engine {
             for (int q = 0; q < 3; ++q) m.n[q] = isM ? N[q] + (q == m.c) : N[q] + (q != m.c);
             m.n[m.a] = np[m.a][m.s];
             m.dev = isM ? phM[m.c][m.a][m.s] : phE[m.c][m.a][m.s];
+            m.dev2 = (!isM && fused) ? phE2[m.c][m.a][m.s] : nullptr;
             m.dev_elems = phSize[isM][m.c][m.a][m.s];
             m.kind = m.a == 2 ? 1 : (m.a == 1 ? 2 : 3);
             return true;
@@ -364,6 +376,7 @@ struct Engine3 : fdtd3d_engine {
             if (off >= 0) st[(size_t)off] = (T)host[o];
         }
         FDTD_HIP(hipMemcpy(m.dev, st.data(), st.size() * sizeof(T), hipMemcpyHostToDevice));
+        if (m.dev2) FDTD_HIP(hipMemcpy(m.dev2, st.data(), st.size() * sizeof(T), hipMemcpyHostToDevice));
         return FDTD_OK;
     }
 
@@ -552,6 +565,47 @@ struct Engine3 : fdtd3d_engine {
         return launch_h(a, kl0, kl1, s);
     }
 
+    template <int FV>
+    void launch_fused(K3<T> a, hipStream_t s) {
+        a.nbx = px / (kLanes * FV);
+        const unsigned nblk = (unsigned)a.nbx * a.nby * a.nbz;
+        const size_t lds = (size_t)2 * wpbf * 2 * kLanes * FV * sizeof(T);
+        if (wpbf > 8) {
+            if (d.has_mu) hipLaunchKernelGGL((k3_fused<T, true, 16, FV>), dim3(nblk), dim3(kLanes * wpbf), lds, s, a);
+            else hipLaunchKernelGGL((k3_fused<T, false, 16, FV>), dim3(nblk), dim3(kLanes * wpbf), lds, s, a);
+        } else {
+            if (d.has_mu) hipLaunchKernelGGL((k3_fused<T, true, 8, FV>), dim3(nblk), dim3(kLanes * wpbf), lds, s, a);
+            else hipLaunchKernelGGL((k3_fused<T, false, 8, FV>), dim3(nblk), dim3(kLanes * wpbf), lds, s, a);
+        }
+    }
+    // One launch per time step (whole grid on this device): D and B cross HBM once.
+    int step(int n, hipStream_t s) override {
+        if (!fused) {
+            if (int rc = half_e(n, FDTD3D_PART_ALL, s)) return rc;
+            return half_h(FDTD3D_PART_ALL, s);
+        }
+        K3<T> a = args();
+        a.src_on = (n >= 0 && n < (int)wf.size()) ? 1 : 0;
+        a.jx = a.src_on ? a.dt * wf[n] : (T)0;
+        for (int c = 0; c < 3; ++c) {
+            a.Dn[c] = alt[c]; a.Bn[c] = alt[6 + c];
+            for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) a.phEn[c][ax][sd] = phE2[c][ax][sd];
+        }
+        a.wpb = wpbf;
+        a.nby = (ny1 + (wpbf - 1) - 1) / (wpbf - 1);
+        a.kl0 = 1; a.kl1 = nzp;
+        a.nbz = (a.kl1 - a.kl0 + a.chunk - 1) / a.chunk;
+        timer.begin(2, s);
+        if (fvec == V) launch_fused<V>(a, s); else launch_fused<V / 2>(a, s);
+        timer.end(s);
+        FDTD_HIP(hipGetLastError());
+        for (int c = 0; c < 3; ++c) {
+            std::swap(fld[c], alt[c]); std::swap(fld[6 + c], alt[6 + c]);
+            for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) std::swap(phE[c][ax][sd], phE2[c][ax][sd]);
+        }
+        return FDTD_OK;
+    }
+
     int halo(int which, int comp, void** p, size_t* nbytes) override {
         if (comp < 0 || comp > 1) return fail(FDTD_ERR_ARG, "halo: comp must be 0 or 1");
         T* base = nullptr;
@@ -585,7 +639,8 @@ int check_desc(const fdtd3d_desc* d) {
         return fail(FDTD_ERR_ARG, "x extent %d too small for separate low/high CPML strips of %d and %d layers", d->Nx, d->n_pml[0], d->n_pml[1]);
     if (d->z_lo < 0 || d->z_hi > d->Nz || d->z_lo >= d->z_hi) return fail(FDTD_ERR_ARG, "bad slab [%d,%d) of %d layers", d->z_lo, d->z_hi, d->Nz);
     if (d->k_Jx < 0 || d->k_Jx > d->Nz) return fail(FDTD_ERR_ARG, "source plane %d outside [0,%d]", d->k_Jx, d->Nz);
-    if (d->mode != FDTD3D_MODE_FULL && d->mode != FDTD3D_MODE_LEAN) return fail(FDTD_ERR_ARG, "unknown storage mode %d", d->mode);
+    if (d->mode != FDTD3D_MODE_FULL && d->mode != FDTD3D_MODE_LEAN && d->mode != FDTD3D_MODE_FUSED) return fail(FDTD_ERR_ARG, "unknown storage mode %d", d->mode);
+    if (d->mode == FDTD3D_MODE_FUSED && (d->z_lo != 0 || d->z_hi != d->Nz)) return fail(FDTD_ERR_ARG, "fused stepping needs the whole grid on one device; slabs use the lean mode");
     if (!(d->dx > 0 && d->dy > 0 && d->dz > 0 && d->dt > 0 && d->mu0 > 0)) return fail(FDTD_ERR_ARG, "dx, dy, dz, dt, mu0 must be positive");
     return FDTD_OK;
 }
@@ -624,10 +679,8 @@ int fdtd3d_fill_materials(fdtd3d_handle h, uint64_t seed, double elo, double ehi
 int fdtd3d_step(fdtd3d_handle h, int n0, int count, void* stream) {
     if (!h) return fail(FDTD_ERR_ARG, "null handle");
     if (h->d.z_lo != 0 || h->d.z_hi != h->d.Nz) return fail(FDTD_ERR_STATE, "fdtd3d_step needs the whole grid on this device; slab drivers use fdtd3d_half_e / fdtd3d_half_h");
-    for (int n = n0; n < n0 + count; ++n) {
-        if (int rc = h->half_e(n, FDTD3D_PART_ALL, (hipStream_t)stream)) return rc;
-        if (int rc = h->half_h(FDTD3D_PART_ALL, (hipStream_t)stream)) return rc;
-    }
+    for (int n = n0; n < n0 + count; ++n)
+        if (int rc = h->step(n, (hipStream_t)stream)) return rc;
     return FDTD_OK;
 }
 int fdtd3d_half_e(fdtd3d_handle h, int n, int part, void* stream) { return h ? h->half_e(n, part, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }

@@ -48,6 +48,10 @@ struct K3 {
     int nbx, nby, nbz;
     int remap;         // 1: hand each XCD a contiguous range of tiles
     int wpb;           // waves (= rows) per workgroup
+    // fused whole-step kernel only: the buffers this step writes (D, B and the D-side CPML state ping-pong)
+    T* Dn[3];
+    T* Bn[3];
+    T* phEn[3][3][2];
 };
 
 template <typename T, int V>

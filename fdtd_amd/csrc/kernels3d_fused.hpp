@@ -1,0 +1,342 @@
+// kernels3d_fused.hpp -- one kernel per time step: E-half and H-half of the 3-D update fused.
+//
+// The two half-step kernels read and write D and B once each AND read the other family once more
+// (the E-half reads B, the H-half reads D): 24 words per cell with eps and mu grids.  Here a
+// workgroup marches through its planes doing, per plane k,
+//     D_new(k) = D_old(k) + curl H_old      (H_old = B_old / mu, as the E-half)
+//     B_new(k-1) = B_old(k-1) - curl E_new  (E_new = D_new / eps, as the H-half, one plane behind)
+// so D, B, eps and mu cross HBM once per step: 18 words per cell plus halos.  What the lagging B
+// update needs from the planes already visited travels on chip: E_new(k-1), B_old(k-1) and the
+// two H_old(k-1) components stay in registers; the E_new row above (j+1) comes through LDS from the
+// wave that owns that row; the column to the right (i+1) is one cross-lane shift.
+//
+// Halos are recomputed, never exchanged between workgroups: the last wave of a workgroup only
+// produces E_new of the first row of the next tile, lane 63 recomputes Ey/Ez of the first column of
+// the next x tile (a scalar side path), and a chunk of planes ends with one extra D iteration.
+// Because a halo recomputation must see the *old* D, B and D-side CPML state of cells another
+// workgroup may already have advanced, those arrays ping-pong between two buffers (read old, write
+// new; the host swaps after the launch).  The B-side CPML state is only touched by its owner and is
+// updated in place.  Per-cell arithmetic is the same sequence of operations as in the half-step
+// kernels, so the results are bit-identical to them (and to the reference in fp64).
+#pragma once
+#include "kernels3d.hpp"
+
+namespace fdtd {
+
+// ---- addressing ------------------------------------------------------------------------------
+// Everything but the lane's position inside its wave's row segment is wave-uniform (workgroup, row
+// and plane).  Array bases are therefore formed on the scalar unit at the point of use and pinned
+// into scalar registers, and every vector access is "scalar base + 32-bit lane offset" in the
+// global address space.  The kernel argument block is re-read through a pointer pinned once per
+// plane, so that the several dozen array pointers are fetched (scalar cache) where they are needed
+// instead of living in registers across the loop.
+#define FDTD_AS(n) __attribute__((address_space(n)))
+
+template <typename T, int V>
+__device__ __forceinline__ Pack<T, V> ldg(const T* ubase, unsigned lo) {
+    typedef T vec __attribute__((ext_vector_type(V)));
+    FDTD_AS(1) const T* g = (FDTD_AS(1) const T*)ubase;
+    asm volatile("" : "+s"(g));
+    const vec x = *(FDTD_AS(1) const vec*)(g + lo);
+    Pack<T, V> r;
+#pragma unroll
+    for (int e = 0; e < V; ++e) r.v[e] = x[e];
+    return r;
+}
+template <typename T, int V>
+__device__ __forceinline__ void stg(T* ubase, unsigned lo, const Pack<T, V>& r) {
+    typedef T vec __attribute__((ext_vector_type(V)));
+    FDTD_AS(1) T* g = (FDTD_AS(1) T*)ubase;
+    asm volatile("" : "+s"(g));
+    vec x;
+#pragma unroll
+    for (int e = 0; e < V; ++e) x[e] = r.v[e];
+    *(FDTD_AS(1) vec*)(g + lo) = x;
+}
+template <typename T>
+__device__ __forceinline__ T ldg1(const T* uaddr) {
+    FDTD_AS(1) const T* g = (FDTD_AS(1) const T*)uaddr;
+    asm volatile("" : "+s"(g));
+    return *g;
+}
+template <typename T> using ArgBlock = const FDTD_AS(4) K3<T>*;
+template <typename T> using Slots = T* const FDTD_AS(4)*;      // two consecutive pointers: low side, high side
+
+// Uniform-zone term with separate input/output CPML state and an optional store.  `in`/`out` point
+// at the [low, high] pointer pair of the state arrays in the argument block; `off_n`/`off_p` are the
+// uniform element offsets of the wave's segment in them.
+template <int SIGN, typename T, int V>
+__device__ __forceinline__ void term_u2(Pack<T, V>& d, const Pack<T, V>& curl, bool skip0, int zone, int l,
+                                        const T* __restrict__ face, int kb, T cmid, T dt,
+                                        Slots<T> in, Slots<T> out, size_t off_n, size_t off_p, unsigned lo, bool store) {
+    if (zone == Z_NONE) return;
+    const T d0 = d.v[0];
+    if (zone == Z_MID) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) { const T v = cmid * curl.v[e]; d.v[e] = SIGN > 0 ? d.v[e] + v : d.v[e] - v; }
+    } else {
+        const int side = zone == Z_POS;
+        const T* t = face + side * 6 * kMaxLayers + kb * kMaxLayers + l;
+        const T b = t[0], a = t[kMaxLayers], C = t[2 * kMaxLayers];
+        const size_t off = side ? off_p : off_n;
+        Pack<T, V> ph = ldg<T, V>(in[side] + off, lo);
+        const T p0 = ph.v[0];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const T p = b * ph.v[e] + a * curl.v[e];
+            ph.v[e] = p;
+            const T v = C * curl.v[e] + dt * p;
+            d.v[e] = SIGN > 0 ? d.v[e] + v : d.v[e] - v;
+        }
+        if (skip0) ph.v[0] = p0;
+        if (store) stg<T, V>(out[side] + off, lo, ph);
+    }
+    if (skip0) d.v[0] = d0;
+}
+// The same for one scalar sample whose CPML state is read but never written (halo column).
+template <int SIGN, typename T>
+__device__ __forceinline__ void term_u1(T& d, T curl, int zone, int l, const T* __restrict__ face, T cmid, T dt,
+                                        Slots<T> in, size_t off_n, size_t off_p) {
+    if (zone == Z_NONE) return;
+    T v;
+    if (zone == Z_MID) v = cmid * curl;
+    else {
+        const int side = zone == Z_POS;
+        const T* t = face + side * 6 * kMaxLayers + l;
+        const T p = t[0] * ldg1<T>(in[side] + (side ? off_p : off_n)) + t[kMaxLayers] * curl;
+        v = t[2 * kMaxLayers] * curl + dt * p;
+    }
+    d = SIGN > 0 ? d + v : d - v;
+}
+// x term with per-column C in registers; b and a are only fetched by lanes inside a CPML strip
+// (`on_n`/`on_p`: this lane's pack lies in the low/high strip).  Every column carries its own
+// coefficients: CPML columns the tabulated ones, plain columns (0, 0, dt/dx), skipped columns zeros.
+template <int SIGN, typename T, int V>
+__device__ __forceinline__ void term_x2(Pack<T, V>& d, const Pack<T, V>& curl, const Pack<T, V>& xC, const T* xr_b, int px,
+                                        T dt, bool on_n, bool on_p, Slots<T> in, Slots<T> out, size_t off_n, ptrdiff_t off_p, unsigned lo, bool store) {
+    if (on_n || on_p) {
+        const Pack<T, V> b = ldg<T, V>(xr_b, lo), a = ldg<T, V>(xr_b + px, lo);
+        Pack<T, V> ph = on_n ? ldg<T, V>(in[0] + off_n, lo) : ldg<T, V>(in[1] + off_p, lo);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const T p = b.v[e] * ph.v[e] + a.v[e] * curl.v[e];
+            ph.v[e] = p;
+            const T v = xC.v[e] * curl.v[e] + dt * p;
+            d.v[e] = SIGN > 0 ? d.v[e] + v : d.v[e] - v;
+        }
+        if (store) { if (on_n) stg<T, V>(out[0] + off_n, lo, ph); else stg<T, V>(out[1] + off_p, lo, ph); }
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) { const T v = xC.v[e] * curl.v[e]; d.v[e] = SIGN > 0 ? d.v[e] + v : d.v[e] - v; }
+    }
+}
+// H = B/mu of the wave's row segment at uniform element offset `uo`, and of one sample.
+template <typename T, int V, bool MU>
+__device__ __forceinline__ Pack<T, V> load_hu(ArgBlock<T> ap, int c, size_t uo, unsigned lo, T mu0) {
+    const Pack<T, V> b = ldg<T, V>(ap->B[c] + uo, lo);
+    return MU ? divide<T, V>(b, ldg<T, V>(ap->mu[c] + uo, lo)) : divide<T, V>(b, mu0);
+}
+template <typename T, bool MU>
+__device__ __forceinline__ T load_hu1(ArgBlock<T> ap, int c, size_t uo, T mu0) {
+    const T b = ldg1<T>(ap->B[c] + uo);
+    return MU ? b / ldg1<T>(ap->mu[c] + uo) : b / mu0;
+}
+
+template <typename T, bool MU, int MAXW, int V>
+__global__ void __launch_bounds__(kLanes * MAXW) __attribute__((amdgpu_waves_per_eu(4, 4))) k3_fused(const K3<T> a) {
+    constexpr int TW = kLanes * V;                       // columns per wave
+    using P = Pack<T, V>;
+    extern __shared__ unsigned char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);            // [2 planes][W rows][2 comps][TW]
+    ArgBlock<T> ap = (ArgBlock<T>)__builtin_amdgcn_kernarg_segment_ptr();
+
+    const unsigned lane = threadIdx.x & (kLanes - 1);
+    const unsigned lo = lane * V;                        // this lane's columns inside the wave's segment
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), W = a.wpb;
+    unsigned bid = a.remap ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int bx = bid % a.nbx; bid /= a.nbx;
+    const int by = bid % a.nby;
+    const int bz = bid / a.nby;
+    const int c0 = bx * TW;                              // first column of the wave's segment
+    const int i0 = c0 + (int)lo;
+    const int jr = by * (W - 1) + w;                     // the last wave is the halo row of the next tile
+    const bool halo_row = w == W - 1;
+    const bool row_ok = jr < a.ny1;
+    const int j = row_ok ? jr : a.ny1 - 1;               // waves past the box keep valid addresses and join every barrier
+    const int klb = a.kl0 + bz * a.chunk, kle = min(klb + a.chunk, a.kl1);
+    const int kl_end = kle < a.nzp ? kle + 1 : kle;      // one extra D iteration closes the chunk
+    const size_t sz = (size_t)a.ny1 * a.px;
+    const int Nx = a.Nx, Ny = a.Ny, Nz = a.Nz, px = a.px;
+    const bool first = i0 == 0;
+    const bool in_n = a.np[0][0] > 0 && i0 < a.xwn;
+    const bool in_p = a.np[0][1] > 0 && i0 >= a.xp0 && i0 < a.xp0 + a.xwp;
+    const P xCe = ldg<T, V>(a.xrow + 2 * (size_t)px + c0, lo), xCm = ldg<T, V>(a.xrow + 5 * (size_t)px + c0, lo);
+    const bool edge_wave = c0 + TW < Nx;                 // the next x tile exists
+    const bool edge = lane == kLanes - 1 && edge_wave;   // this lane recomputes Ey, Ez of its first column
+    T xbe = (T)0, xae = (T)0, xce = (T)0;                // x coefficients of that column
+    bool e_in_n = false, e_in_p = false;
+    if (edge_wave) {
+        const int ih = c0 + TW;
+        xbe = ldg1<T>(a.xrow + ih); xae = ldg1<T>(a.xrow + (size_t)px + ih); xce = ldg1<T>(a.xrow + 2 * (size_t)px + ih);
+        e_in_n = a.np[0][0] > 0 && ih < a.xwn;
+        e_in_p = a.np[0][1] > 0 && ih >= a.xp0 && ih < a.xp0 + a.xwp;
+    }
+
+    int lye, lyh;
+    const int zye = zone_e(j, Ny, a.np[1][0], a.np[1][1], lye);
+    const int zyh = zone_h(j, Ny, a.np[1][0], a.np[1][1], true, lyh);
+    const T* face_y = a.tab + (size_t)(1 * 2) * 6 * kMaxLayers;
+    const T* face_z = a.tab + (size_t)(2 * 2) * 6 * kMaxLayers;
+    const bool row_lt = j < Ny, row_in = j >= 1 && j < Ny;
+
+    size_t ro = ((size_t)klb * a.ny1 + j) * px + c0;     // uniform offset of the wave's row segment in a field array
+    P hx_km = zero_pack<T, V>(), hy_km = zero_pack<T, V>();
+    T hxe_km = (T)0;
+    if (klb + a.zoff >= 1) {
+        hx_km = load_hu<T, V, MU>(ap, 0, ro - sz, lo, a.mu0); hy_km = load_hu<T, V, MU>(ap, 1, ro - sz, lo, a.mu0);
+        if (edge) hxe_km = load_hu1<T, MU>(ap, 0, ro - sz + TW, a.mu0);
+    }
+    P bo_km[3] = {zero_pack<T, V>(), zero_pack<T, V>(), zero_pack<T, V>()};
+    P en_km[3] = {zero_pack<T, V>(), zero_pack<T, V>(), zero_pack<T, V>()};
+    T eye_km = (T)0, eze_km = (T)0;
+
+    for (int kl = klb; kl < kl_end; ++kl, ro += sz) {
+        asm volatile("" : "+s"(ap));                     // array pointers are fetched again below, where they are used
+        const int k = kl + a.zoff;
+        const bool own_d = row_ok && !halo_row && kl < kle;
+        int lke, lkh;
+        const int zke = zone_e(k, Nz, a.np[2][0], a.np[2][1], lke);
+        const int zkh = zone_h(k - 1, Nz, a.np[2][0], a.np[2][1], true, lkh);
+        const bool pl_lt = k < Nz, pl_in = k >= 1 && k < Nz;
+
+        // ------------------------------------------------------------ loads of plane k
+        P bo[3];
+        bo[0] = ldg<T, V>(ap->B[0] + ro, lo); bo[1] = ldg<T, V>(ap->B[1] + ro, lo); bo[2] = ldg<T, V>(ap->B[2] + ro, lo);
+        P hx, hy, hz;
+        if (MU) { hx = divide<T, V>(bo[0], ldg<T, V>(ap->mu[0] + ro, lo)); hy = divide<T, V>(bo[1], ldg<T, V>(ap->mu[1] + ro, lo)); hz = divide<T, V>(bo[2], ldg<T, V>(ap->mu[2] + ro, lo)); }
+        else { hx = divide<T, V>(bo[0], a.mu0); hy = divide<T, V>(bo[1], a.mu0); hz = divide<T, V>(bo[2], a.mu0); }
+        P hx_jm = zero_pack<T, V>(), hz_jm = zero_pack<T, V>();
+        if (j >= 1) { hx_jm = load_hu<T, V, MU>(ap, 0, ro - px, lo, a.mu0); hz_jm = load_hu<T, V, MU>(ap, 2, ro - px, lo, a.mu0); }
+        P dx = ldg<T, V>(ap->D[0] + ro, lo), dy = ldg<T, V>(ap->D[1] + ro, lo), dz = ldg<T, V>(ap->D[2] + ro, lo);
+        T hy_l = __shfl_up(hy.v[V - 1], 1), hz_l = __shfl_up(hz.v[V - 1], 1);
+        if (lane == 0) {
+            hy_l = c0 > 0 ? load_hu1<T, MU>(ap, 1, ro - 1, a.mu0) : (T)0;
+            hz_l = c0 > 0 ? load_hu1<T, MU>(ap, 2, ro - 1, a.mu0) : (T)0;
+        }
+
+        const size_t oz = ((size_t)lke * a.ny1 + j) * px + c0;                 // z-face state, D side (uniform)
+        const size_t oy0 = ((size_t)kl * a.np[1][0] + lye) * px + c0, oy1 = ((size_t)kl * a.np[1][1] + lye) * px + c0;
+        const size_t oxn = ((size_t)kl * a.ny1 + j) * a.xwn + c0;
+        const ptrdiff_t oxp = (ptrdiff_t)(((size_t)kl * a.ny1 + j) * a.xwp) + (c0 - a.xp0);
+
+        // ------------------------------------------------------------ D_new(k), E_new(k)
+        if (row_lt) term_u2<-1, T, V>(dx, diff<T, V>(hy, hy_km), false, zke, lke, face_z, 0, a.dtd[2], a.dt, ap->phE[0][2], ap->phEn[0][2], oz, oz, lo, own_d);
+        if (pl_in) term_u2<+1, T, V>(dx, diff<T, V>(hz, hz_jm), false, zye, lye, face_y, 0, a.dtd[1], a.dt, ap->phE[0][1], ap->phEn[0][1], oy0, oy1, lo, own_d);
+        if (a.src_on && k == a.kJ) {
+            const P m = ldg<T, V>(a.mag + (size_t)j * px + c0, lo);
+#pragma unroll
+            for (int e = 0; e < V; ++e) dx.v[e] = dx.v[e] + a.jx * m.v[e];
+        }
+        if (row_lt) {
+            term_u2<+1, T, V>(dy, diff<T, V>(hx, hx_km), first, zke, lke, face_z, 0, a.dtd[2], a.dt, ap->phE[1][2], ap->phEn[1][2], oz, oz, lo, own_d);
+            if (pl_in) term_x2<-1, T, V>(dy, diff_back_x<T, V>(hz, hz_l), xCe, a.xrow + c0, px, a.dt, in_n, in_p, ap->phE[1][0], ap->phEn[1][0], oxn, oxp, lo, own_d);
+        }
+        if (pl_lt) {
+            if (row_in) term_x2<+1, T, V>(dz, diff_back_x<T, V>(hy, hy_l), xCe, a.xrow + c0, px, a.dt, in_n, in_p, ap->phE[2][0], ap->phEn[2][0], oxn, oxp, lo, own_d);
+            term_u2<-1, T, V>(dz, diff<T, V>(hx, hx_jm), first, zye, lye, face_y, 0, a.dtd[1], a.dt, ap->phE[2][1], ap->phEn[2][1], oy0, oy1, lo, own_d);
+        }
+        if (own_d) {
+            stg<T, V>(ap->Dn[0] + ro, lo, dx);
+            if (row_lt) stg<T, V>(ap->Dn[1] + ro, lo, dy);
+            if (pl_lt) stg<T, V>(ap->Dn[2] + ro, lo, dz);
+        }
+        P en[3];
+        en[0] = divide<T, V>(dx, ldg<T, V>(ap->eps[0] + ro, lo));
+        en[1] = divide<T, V>(dy, ldg<T, V>(ap->eps[1] + ro, lo));
+        en[2] = divide<T, V>(dz, ldg<T, V>(ap->eps[2] + ro, lo));
+
+        // ------------------------------------------------------------ halo column of the next x tile (lane 63 only)
+        T eye = (T)0, eze = (T)0, hxe = (T)0;
+        if (edge) {
+            const size_t ie = ro + TW;
+            hxe = load_hu1<T, MU>(ap, 0, ie, a.mu0);
+            const T hye = load_hu1<T, MU>(ap, 1, ie, a.mu0), hze = load_hu1<T, MU>(ap, 2, ie, a.mu0);
+            T d1 = ldg1<T>(ap->D[1] + ie), d2 = ldg1<T>(ap->D[2] + ie);
+            const ptrdiff_t oxe = e_in_n ? (ptrdiff_t)oxn + TW : oxp + TW;
+            if (row_lt) {
+                term_u1<+1, T>(d1, hxe - hxe_km, zke, lke, face_z, a.dtd[2], a.dt, ap->phE[1][2], oz + TW, oz + TW);
+                if (pl_in) {
+                    const T curl = hze - hz.v[V - 1];
+                    const T ph = (e_in_n || e_in_p) ? ldg1<T>(ap->phE[1][0][e_in_p] + oxe) : (T)0;
+                    const T p = xbe * ph + xae * curl;
+                    d1 = d1 - (xce * curl + a.dt * p);
+                }
+            }
+            if (pl_lt) {
+                if (row_in) {
+                    const T curl = hye - hy.v[V - 1];
+                    const T ph = (e_in_n || e_in_p) ? ldg1<T>(ap->phE[2][0][e_in_p] + oxe) : (T)0;
+                    const T p = xbe * ph + xae * curl;
+                    d2 = d2 + (xce * curl + a.dt * p);
+                }
+                const T hxe_jm = j >= 1 ? load_hu1<T, MU>(ap, 0, ie - px, a.mu0) : (T)0;
+                term_u1<-1, T>(d2, hxe - hxe_jm, zye, lye, face_y, a.dtd[1], a.dt, ap->phE[2][1], oy0 + TW, oy1 + TW);
+            }
+            eye = d1 / ldg1<T>(ap->eps[1] + ie);
+            eze = d2 / ldg1<T>(ap->eps[2] + ie);
+        }
+
+        // ------------------------------------------------------------ B_new(k-1)
+        if (kl > klb && row_ok && !halo_row) {
+            asm volatile("" : "+s"(ap));
+            // the row above, plane k-1, published by the next wave at the end of the previous iteration
+            const T* src = smem + ((size_t)(((kl - 1) & 1) * W + (w + 1)) * 2) * TW + lo;
+            const P ex_jp = ldv<T, V>(src), ez_jp = ldv<T, V>(src + TW);
+            const size_t rb = ro - sz;
+            const int klm = kl - 1, km = k - 1;
+            const bool bl_lt = km < Nz, bl_in = km >= 1 && km < Nz;
+            T ey_r = __shfl_down(en_km[1].v[0], 1), ez_r = __shfl_down(en_km[2].v[0], 1);
+            if (lane == kLanes - 1) { ey_r = eye_km; ez_r = eze_km; }
+            const size_t pz = ((size_t)lkh * a.ny1 + j) * px + c0;
+            const size_t py0 = ((size_t)klm * a.np[1][0] + lyh) * px + c0, py1 = ((size_t)klm * a.np[1][1] + lyh) * px + c0;
+            const size_t pxn = ((size_t)klm * a.ny1 + j) * a.xwn + c0;
+            const ptrdiff_t pxp = (ptrdiff_t)(((size_t)klm * a.ny1 + j) * a.xwp) + (c0 - a.xp0);
+            const T* xrm = a.xrow + 3 * (size_t)px + c0;
+            if (row_lt && bl_lt) {
+                P b = bo_km[0];
+                term_u2<+1, T, V>(b, diff<T, V>(en[1], en_km[1]), first, zkh, lkh, face_z, 3, a.dtd[2], a.dt, ap->phM[0][2], ap->phM[0][2], pz, pz, lo, true);
+                term_u2<-1, T, V>(b, diff<T, V>(ez_jp, en_km[2]), first, zyh, lyh, face_y, 3, a.dtd[1], a.dt, ap->phM[0][1], ap->phM[0][1], py0, py1, lo, true);
+                stg<T, V>(ap->Bn[0] + rb, lo, b);
+            }
+            if (bl_lt) {
+                P b = bo_km[1];
+                if (row_in) {
+                    term_x2<+1, T, V>(b, diff_fwd_x<T, V>(en_km[2], ez_r), xCm, xrm, px, a.dt, in_n, in_p, ap->phM[1][0], ap->phM[1][0], pxn, pxp, lo, true);
+                    term_u2<-1, T, V>(b, diff<T, V>(en[0], en_km[0]), false, zkh, lkh, face_z, 3, a.dtd[2], a.dt, ap->phM[1][2], ap->phM[1][2], pz, pz, lo, true);
+                }
+                stg<T, V>(ap->Bn[1] + rb, lo, b);
+            }
+            if (row_lt) {
+                P b = bo_km[2];
+                if (bl_in) {
+                    term_u2<+1, T, V>(b, diff<T, V>(ex_jp, en_km[0]), false, zyh, lyh, face_y, 3, a.dtd[1], a.dt, ap->phM[2][1], ap->phM[2][1], py0, py1, lo, true);
+                    term_x2<-1, T, V>(b, diff_fwd_x<T, V>(en_km[1], ey_r), xCm, xrm, px, a.dt, in_n, in_p, ap->phM[2][0], ap->phM[2][0], pxn, pxp, lo, true);
+                }
+                stg<T, V>(ap->Bn[2] + rb, lo, b);
+            }
+        }
+
+        // ------------------------------------------------------------ hand-over to the next iteration
+        {
+            T* dst = smem + ((size_t)((kl & 1) * W + w) * 2) * TW + lo;
+            stv<T, V>(dst, en[0]); stv<T, V>(dst + TW, en[2]);
+        }
+        hx_km = hx; hy_km = hy; hxe_km = hxe;
+        bo_km[0] = bo[0]; bo_km[1] = bo[1]; bo_km[2] = bo[2];
+        en_km[0] = en[0]; en_km[1] = en[1]; en_km[2] = en[2];
+        eye_km = eye; eze_km = eze;
+        __syncthreads();
+    }
+}
+
+}  // namespace fdtd

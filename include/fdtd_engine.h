@@ -70,6 +70,8 @@ enum {
 /* Storage modes. */
 #define FDTD3D_MODE_FULL 0   /* D,E,B,H all resident (the reference's formulation)            */
 #define FDTD3D_MODE_LEAN 1   /* only D,B resident; E=D/eps, H=B/mu recomputed where consumed */
+#define FDTD3D_MODE_FUSED 2  /* lean storage with D, B ping-pong buffers; fdtd3d_step runs one
+                                kernel per time step (whole grid on one device only)          */
 
 typedef struct fdtd3d_desc {
     int32_t struct_size;      /* sizeof(fdtd3d_desc), for forward compatibility             */

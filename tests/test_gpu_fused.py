@@ -1,0 +1,99 @@
+"""One-kernel-per-step (fused E+H) stepping against the golden vectors and the twin (needs a GPU)."""
+import numpy as np
+import pytest
+
+import fdtd_amd
+from fdtd_amd.engine import MODE_FUSED
+from oracle import pyoracle as po
+from tests import util
+from tests.test_gpu_parity import FIX3D, engine3d_from_meta
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", FIX3D)
+@pytest.mark.parametrize("prec", [32, 64])
+@pytest.mark.parametrize("rows,chunk", [(16, 8), (8, 3), (3, 1)])
+def test_fused_step_equals_reference_3d(name, prec, rows, chunk):
+    """fp64 against the reference vectors, fp32 against the fp32 twin, bit for bit, for several
+    workgroup shapes (rows per group, planes per chunk) so that every halo path is crossed."""
+    meta, ins, outs, _ = util.load_fixture(name)
+    eng = engine3d_from_meta(meta, prec, mode=MODE_FUSED)
+    eng.tune(chunk, 1, rows)
+    util.feed(eng, ins)
+    got = util.run_snapshots(eng, meta, outs)
+    if prec == 64:
+        ref = outs
+    else:
+        tw = util.twin3d_from_meta(meta, 32)
+        util.feed(tw, ins)
+        ref = util.run_snapshots(tw, meta, outs)
+    for key in outs:
+        util.assert_equal_arrays(got[key], ref[key], f"{name} fused fp{prec} step {key[0]} array {key[1]}")
+
+
+@pytest.mark.parametrize("prec", [32, 64])
+def test_fused_mu_grid_3d(prec):
+    meta, ins, outs, _ = util.load_fixture("g3_3d_hetero")
+    eng = engine3d_from_meta(meta, prec, has_mu=True, mode=MODE_FUSED)
+    tw = util.twin3d_from_meta(meta, prec, has_mu=True)
+    util.feed(eng, ins)
+    util.feed(tw, ins)
+    eng.fill_materials(77, meta["eps0"], 4 * meta["eps0"], meta["mu0"], 2 * meta["mu0"])
+    tw.fill_materials(77, meta["eps0"], 4 * meta["eps0"], meta["mu0"], 2 * meta["mu0"])
+    eng.step(0, meta["steps"])
+    tw.step(0, meta["steps"])
+    for id_ in po.FIELDS3D + po.ALL_PHI3D:
+        util.assert_equal_arrays(eng.get(id_), tw.get(id_), f"fused mu grid array {id_}")
+
+
+@pytest.mark.parametrize("prec,N,npml", [
+    (32, (300, 9, 11), (5, 6, 2, 2, 3, 3)),       # two x tiles, plain columns at the tile boundary
+    (32, (270, 20, 6), (3, 20, 1, 0, 0, 2)),      # x tile boundary (256) inside the high CPML strip
+    (64, (140, 6, 19), (10, 20, 0, 3, 4, 4)),     # fp64 tiles are 128 columns: boundary inside the strip
+    (32, (7, 6, 5), (0, 0, 0, 0, 0, 0)),
+    (64, (12, 33, 9), (4, 4, 4, 4, 4, 4)),        # more rows than one workgroup holds
+])
+@pytest.mark.parametrize("rows,chunk", [(16, 8), (5, 2)])
+def test_fused_ragged_shapes_3d(prec, N, npml, rows, chunk):
+    K = po.consts()
+    d = (5e-8, 6e-8, 7e-8)
+    dt = 5e-8 / (2 * K["c0"])
+    steps = 25
+    kJ = N[2] // 2
+    eng = fdtd_amd.Engine3D(N, npml, d, dt, K["mu0"], kJ, steps, precision=prec, mode=MODE_FUSED)
+    eng.tune(chunk, 1, rows)
+    tw = po.Twin3D(prec, N, npml, d, dt, K["mu0"], kJ, steps)
+    rng = np.random.default_rng(5)
+    for be in (eng, tw):
+        for a in range(3):
+            for s in range(2):
+                tabs = po.cpml_face(npml[a * 2 + s], s, d[a], d[a], dt)
+                for k in range(6):
+                    if npml[a * 2 + s]:
+                        be.set(po.tab_id(a, s, k), tabs[k])
+    wf, mag = po.default_source3d(N[0], N[1], steps, d, dt)
+    mag = rng.random(mag.shape)
+    eps = [K["eps0"] * (1 + 3 * rng.random(po.shape3d(po.EPS_X + c, N, npml))) for c in range(3)]
+    for be in (eng, tw):
+        be.set(po.JX_WF, wf)
+        be.set(po.JX_MAG, mag)
+        for c in range(3):
+            be.set(po.EPS_X + c, eps[c])
+    # an odd number of steps first, so that reads after the run come from the second buffer
+    eng.step(0, 11)
+    tw.step(0, 11)
+    for id_ in po.FIELDS3D + po.ALL_PHI3D:
+        if eng.size(id_):
+            util.assert_equal_arrays(eng.get(id_), tw.get(id_), f"N={N} step 11 array {id_}")
+    eng.step(11, steps - 11)
+    tw.step(11, steps - 11)
+    for id_ in po.FIELDS3D + po.ALL_PHI3D:
+        if eng.size(id_):
+            util.assert_equal_arrays(eng.get(id_), tw.get(id_), f"N={N} array {id_}")
+
+
+def test_fused_needs_whole_grid():
+    K = po.consts()
+    with pytest.raises(Exception):
+        fdtd_amd.Engine3D((16, 16, 16), (0,) * 6, (1e-7,) * 3, 1e-16, K["mu0"], 4, 3, precision=32, mode=MODE_FUSED, z_lo=0, z_hi=8)
