@@ -119,7 +119,10 @@ struct fdtd3d_engine {
     virtual int half_e(int n, int part, hipStream_t s) = 0;
     virtual int half_h(int part, hipStream_t s) = 0;
     virtual int step(int n, hipStream_t s) = 0;
-    virtual int halo(int which, int comp, void** p, size_t* bytes) = 0;
+    virtual int fused_part(int n, int part, hipStream_t s) = 0;
+    virtual int parity() = 0;
+    virtual int fused_top(hipStream_t s) = 0;
+    virtual int halo(int which, int comp, void** p, size_t* bytes, int at_parity) = 0;
     virtual int reduce(int id, double* sumsq, uint64_t* checksum, hipStream_t s) = 0;
     virtual size_t device_bytes() = 0;
     virtual int tune(int chunk, int remap, int rows) = 0;
@@ -189,6 +192,7 @@ struct Engine3 : fdtd3d_engine {
         xwn = np[0][0] > 0 ? round_up(np[0][0] + 1, 4) : 0;
         xp0 = (d.Nx - np[0][1]) / 4 * 4;
         xwp = np[0][1] > 0 ? round_up(d.Nx - xp0, 4) : 0;
+        if (fused) chunk = 16;           // the closing plane of a chunk is computed twice: longer chunks pay off
         if (const char* e = getenv("FDTD_Z_CHUNK")) { int c = atoi(e); if (c >= 1 && c <= 4096) chunk = c; }
         if (const char* e = getenv("FDTD_XCD_REMAP")) remap = atoi(e) != 0;
         if (const char* e = getenv("FDTD_FUSED_VEC")) { int v = atoi(e); if (v == V || v == V / 2) fvec = v; }
@@ -569,21 +573,41 @@ struct Engine3 : fdtd3d_engine {
     void launch_fused(K3<T> a, hipStream_t s) {
         a.nbx = px / (kLanes * FV);
         const unsigned nblk = (unsigned)a.nbx * a.nby * a.nbz;
-        const size_t lds = (size_t)2 * wpbf * 2 * kLanes * FV * sizeof(T);
-        if (wpbf > 8) {
-            if (d.has_mu) hipLaunchKernelGGL((k3_fused<T, true, 16, FV>), dim3(nblk), dim3(kLanes * wpbf), lds, s, a);
-            else hipLaunchKernelGGL((k3_fused<T, false, 16, FV>), dim3(nblk), dim3(kLanes * wpbf), lds, s, a);
-        } else {
-            if (d.has_mu) hipLaunchKernelGGL((k3_fused<T, true, 8, FV>), dim3(nblk), dim3(kLanes * wpbf), lds, s, a);
-            else hipLaunchKernelGGL((k3_fused<T, false, 8, FV>), dim3(nblk), dim3(kLanes * wpbf), lds, s, a);
-        }
+        const size_t lds = (size_t)2 * wpbf * 3 * kLanes * FV * sizeof(T);
+        auto go = [&](auto kern) {
+            // more than 64 KB of dynamic LDS has to be allowed per kernel
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(nblk), dim3(kLanes * wpbf), lds, s, a);
+        };
+        if (wpbf > 8) { if (d.has_mu) go(k3_fused<T, true, 16, FV>); else go(k3_fused<T, false, 16, FV>); }
+        else { if (d.has_mu) go(k3_fused<T, true, 8, FV>); else go(k3_fused<T, false, 8, FV>); }
     }
-    // One launch per time step (whole grid on this device): D and B cross HBM once.
+    // One launch per time step: D and B cross HBM once.  On a slab the lowest chunk of planes can be
+    // launched first (EDGE) so that its D planes travel while the rest (INTERIOR) is computed; the
+    // buffers change roles when the first part of a step is launched.
+    bool mid_step = false;
+    int flips = 0;
+    int parity() override { return flips & 1; }
     int step(int n, hipStream_t s) override {
-        if (!fused) {
-            if (int rc = half_e(n, FDTD3D_PART_ALL, s)) return rc;
-            return half_h(FDTD3D_PART_ALL, s);
-        }
+        if (fused) return fused_part(n, FDTD3D_PART_ALL, s);
+        if (int rc = half_e(n, FDTD3D_PART_ALL, s)) return rc;
+        return half_h(FDTD3D_PART_ALL, s);
+    }
+    // B of the top layer of a slab that has another one above it (no-op on the last slab)
+    int fused_top(hipStream_t s) override {
+        if (!fused) return fail(FDTD_ERR_STATE, "fused stepping needs an engine created with FDTD3D_MODE_FUSED");
+        if (mid_step) return fail(FDTD_ERR_STATE, "fused: the step's INTERIOR part has not been launched");
+        return last_rank ? FDTD_OK : half_h(FDTD3D_PART_EDGE, s);
+    }
+    int fused_part(int n, int part, hipStream_t s) override {
+        if (!fused) return fail(FDTD_ERR_STATE, "fused stepping needs an engine created with FDTD3D_MODE_FUSED");
+        const int lo = 1, hi = last_rank ? nzp : nzp - 1, cut = std::min(lo + chunk, hi);
+        int kl0, kl1;
+        if (part == FDTD3D_PART_ALL) { kl0 = lo; kl1 = hi; }
+        else if (part == FDTD3D_PART_EDGE) { kl0 = lo; kl1 = cut; }
+        else if (part == FDTD3D_PART_INTERIOR) { kl0 = cut; kl1 = hi; }
+        else return fail(FDTD_ERR_ARG, "fused: bad part %d", part);
+        if ((part == FDTD3D_PART_INTERIOR) != mid_step) return fail(FDTD_ERR_STATE, "fused: a step is EDGE followed by INTERIOR, or ALL");
         K3<T> a = args();
         a.src_on = (n >= 0 && n < (int)wf.size()) ? 1 : 0;
         a.jx = a.src_on ? a.dt * wf[n] : (T)0;
@@ -591,23 +615,37 @@ struct Engine3 : fdtd3d_engine {
             a.Dn[c] = alt[c]; a.Bn[c] = alt[6 + c];
             for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) a.phEn[c][ax][sd] = phE2[c][ax][sd];
         }
+        if (mid_step)      // the roles were exchanged when EDGE was launched
+            for (int c = 0; c < 3; ++c) {
+                std::swap(a.D[c], a.Dn[c]); std::swap(a.B[c], a.Bn[c]);
+                for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) std::swap(a.phE[c][ax][sd], a.phEn[c][ax][sd]);
+            }
         a.wpb = wpbf;
         a.nby = (ny1 + (wpbf - 1) - 1) / (wpbf - 1);
-        a.kl0 = 1; a.kl1 = nzp;
+        a.kl0 = kl0; a.kl1 = kl1;
+        a.kl_stop = hi; a.copy_top = last_rank ? 0 : 1;
         a.nbz = (a.kl1 - a.kl0 + a.chunk - 1) / a.chunk;
-        timer.begin(2, s);
-        if (fvec == V) launch_fused<V>(a, s); else launch_fused<V / 2>(a, s);
-        timer.end(s);
-        FDTD_HIP(hipGetLastError());
-        for (int c = 0; c < 3; ++c) {
-            std::swap(fld[c], alt[c]); std::swap(fld[6 + c], alt[6 + c]);
-            for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) std::swap(phE[c][ax][sd], phE2[c][ax][sd]);
+        if (kl1 > kl0) {
+            timer.begin(2, s);
+            if (fvec == V) launch_fused<V>(a, s); else launch_fused<V / 2>(a, s);
+            timer.end(s);
+            FDTD_HIP(hipGetLastError());
         }
+        if (part != FDTD3D_PART_INTERIOR) {
+            for (int c = 0; c < 3; ++c) {
+                std::swap(fld[c], alt[c]); std::swap(fld[6 + c], alt[6 + c]);
+                for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) std::swap(phE[c][ax][sd], phE2[c][ax][sd]);
+            }
+            ++flips;
+        }
+        mid_step = part == FDTD3D_PART_EDGE;
         return FDTD_OK;
     }
 
-    int halo(int which, int comp, void** p, size_t* nbytes) override {
+    int halo(int which, int comp, void** p, size_t* nbytes, int at_parity) override {
         if (comp < 0 || comp > 1) return fail(FDTD_ERR_ARG, "halo: comp must be 0 or 1");
+        if (at_parity >= 0 && !fused && at_parity != 0) return fail(FDTD_ERR_ARG, "halo: only FUSED engines have a second buffer set");
+        T* const* fld = (fused && at_parity >= 0 && at_parity != parity()) ? alt : this->fld;
         T* base = nullptr;
         int kl = 0;
         switch (which) {
@@ -640,7 +678,6 @@ int check_desc(const fdtd3d_desc* d) {
     if (d->z_lo < 0 || d->z_hi > d->Nz || d->z_lo >= d->z_hi) return fail(FDTD_ERR_ARG, "bad slab [%d,%d) of %d layers", d->z_lo, d->z_hi, d->Nz);
     if (d->k_Jx < 0 || d->k_Jx > d->Nz) return fail(FDTD_ERR_ARG, "source plane %d outside [0,%d]", d->k_Jx, d->Nz);
     if (d->mode != FDTD3D_MODE_FULL && d->mode != FDTD3D_MODE_LEAN && d->mode != FDTD3D_MODE_FUSED) return fail(FDTD_ERR_ARG, "unknown storage mode %d", d->mode);
-    if (d->mode == FDTD3D_MODE_FUSED && (d->z_lo != 0 || d->z_hi != d->Nz)) return fail(FDTD_ERR_ARG, "fused stepping needs the whole grid on one device; slabs use the lean mode");
     if (!(d->dx > 0 && d->dy > 0 && d->dz > 0 && d->dt > 0 && d->mu0 > 0)) return fail(FDTD_ERR_ARG, "dx, dy, dz, dt, mu0 must be positive");
     return FDTD_OK;
 }
@@ -683,11 +720,18 @@ int fdtd3d_step(fdtd3d_handle h, int n0, int count, void* stream) {
         if (int rc = h->step(n, (hipStream_t)stream)) return rc;
     return FDTD_OK;
 }
+int fdtd3d_fused(fdtd3d_handle h, int n, int part, void* stream) { return h ? h->fused_part(n, part, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_fused_top(fdtd3d_handle h, void* stream) { return h ? h->fused_top((hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_buffer_parity(fdtd3d_handle h) { return h ? h->parity() : 0; }
 int fdtd3d_half_e(fdtd3d_handle h, int n, int part, void* stream) { return h ? h->half_e(n, part, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
 int fdtd3d_half_h(fdtd3d_handle h, int part, void* stream) { return h ? h->half_h(part, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
 int fdtd3d_halo(fdtd3d_handle h, int which, int comp, void** p, size_t* bytes) {
     if (!h || !p || !bytes) return fail(FDTD_ERR_ARG, "null argument");
-    return h->halo(which, comp, p, bytes);
+    return h->halo(which, comp, p, bytes, -1);
+}
+int fdtd3d_halo_at(fdtd3d_handle h, int parity, int which, int comp, void** p, size_t* bytes) {
+    if (!h || !p || !bytes || parity < 0 || parity > 1) return fail(FDTD_ERR_ARG, "bad argument");
+    return h->halo(which, comp, p, bytes, parity);
 }
 int fdtd3d_sumsq(fdtd3d_handle h, int id, double* out, void* stream) { return h ? h->reduce(id, out, nullptr, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
 int fdtd3d_checksum(fdtd3d_handle h, int id, uint64_t* out, void* stream) { return h ? h->reduce(id, nullptr, out, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }

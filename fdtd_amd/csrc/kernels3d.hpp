@@ -52,6 +52,8 @@ struct K3 {
     T* Dn[3];
     T* Bn[3];
     T* phEn[3][3][2];
+    int kl_stop;       // planes below this index may be visited for the closing D iteration of a chunk
+    int copy_top;      // plane kl_stop-1 is a top layer whose B is finished later: carry it over unchanged
 };
 
 template <typename T, int V>

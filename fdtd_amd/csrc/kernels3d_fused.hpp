@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(kLanes * MAXW) __attribute__((amdgpu_waves_per
     constexpr int TW = kLanes * V;                       // columns per wave
     using P = Pack<T, V>;
     extern __shared__ unsigned char smem_raw[];
-    T* smem = reinterpret_cast<T*>(smem_raw);            // [2 planes][W rows][2 comps][TW]
+    T* smem = reinterpret_cast<T*>(smem_raw);            // [2 planes][W rows][3 comps][TW]: E_new of the last two planes
     ArgBlock<T> ap = (ArgBlock<T>)__builtin_amdgcn_kernarg_segment_ptr();
 
     const unsigned lane = threadIdx.x & (kLanes - 1);
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(kLanes * MAXW) __attribute__((amdgpu_waves_per
     const bool row_ok = jr < a.ny1;
     const int j = row_ok ? jr : a.ny1 - 1;               // waves past the box keep valid addresses and join every barrier
     const int klb = a.kl0 + bz * a.chunk, kle = min(klb + a.chunk, a.kl1);
-    const int kl_end = kle < a.nzp ? kle + 1 : kle;      // one extra D iteration closes the chunk
+    const int kl_end = kle < a.kl_stop ? kle + 1 : kle;  // one extra D iteration closes the chunk
     const size_t sz = (size_t)a.ny1 * a.px;
     const int Nx = a.Nx, Ny = a.Ny, Nz = a.Nz, px = a.px;
     const bool first = i0 == 0;
@@ -197,7 +197,6 @@ __global__ void __launch_bounds__(kLanes * MAXW) __attribute__((amdgpu_waves_per
         if (edge) hxe_km = load_hu1<T, MU>(ap, 0, ro - sz + TW, a.mu0);
     }
     P bo_km[3] = {zero_pack<T, V>(), zero_pack<T, V>(), zero_pack<T, V>()};
-    P en_km[3] = {zero_pack<T, V>(), zero_pack<T, V>(), zero_pack<T, V>()};
     T eye_km = (T)0, eze_km = (T)0;
 
     for (int kl = klb; kl < kl_end; ++kl, ro += sz) {
@@ -218,6 +217,7 @@ __global__ void __launch_bounds__(kLanes * MAXW) __attribute__((amdgpu_waves_per
         P hx_jm = zero_pack<T, V>(), hz_jm = zero_pack<T, V>();
         if (j >= 1) { hx_jm = load_hu<T, V, MU>(ap, 0, ro - px, lo, a.mu0); hz_jm = load_hu<T, V, MU>(ap, 2, ro - px, lo, a.mu0); }
         P dx = ldg<T, V>(ap->D[0] + ro, lo), dy = ldg<T, V>(ap->D[1] + ro, lo), dz = ldg<T, V>(ap->D[2] + ro, lo);
+        const P epx = ldg<T, V>(ap->eps[0] + ro, lo), epy = ldg<T, V>(ap->eps[1] + ro, lo), epz = ldg<T, V>(ap->eps[2] + ro, lo);
         T hy_l = __shfl_up(hy.v[V - 1], 1), hz_l = __shfl_up(hz.v[V - 1], 1);
         if (lane == 0) {
             hy_l = c0 > 0 ? load_hu1<T, MU>(ap, 1, ro - 1, a.mu0) : (T)0;
@@ -251,9 +251,7 @@ __global__ void __launch_bounds__(kLanes * MAXW) __attribute__((amdgpu_waves_per
             if (pl_lt) stg<T, V>(ap->Dn[2] + ro, lo, dz);
         }
         P en[3];
-        en[0] = divide<T, V>(dx, ldg<T, V>(ap->eps[0] + ro, lo));
-        en[1] = divide<T, V>(dy, ldg<T, V>(ap->eps[1] + ro, lo));
-        en[2] = divide<T, V>(dz, ldg<T, V>(ap->eps[2] + ro, lo));
+        en[0] = divide<T, V>(dx, epx); en[1] = divide<T, V>(dy, epy); en[2] = divide<T, V>(dz, epz);
 
         // ------------------------------------------------------------ halo column of the next x tile (lane 63 only)
         T eye = (T)0, eze = (T)0, hxe = (T)0;
@@ -290,8 +288,11 @@ __global__ void __launch_bounds__(kLanes * MAXW) __attribute__((amdgpu_waves_per
         if (kl > klb && row_ok && !halo_row) {
             asm volatile("" : "+s"(ap));
             // the row above, plane k-1, published by the next wave at the end of the previous iteration
-            const T* src = smem + ((size_t)(((kl - 1) & 1) * W + (w + 1)) * 2) * TW + lo;
-            const P ex_jp = ldv<T, V>(src), ez_jp = ldv<T, V>(src + TW);
+            const T* own = smem + ((size_t)(((kl - 1) & 1) * W + w) * 3) * TW + lo;     // this row, plane k-1
+            const T* src = own + 3 * TW;                                                // the row above
+            const P ex_jp = ldv<T, V>(src), ez_jp = ldv<T, V>(src + 2 * TW);
+            P en_km[3];
+            en_km[0] = ldv<T, V>(own); en_km[1] = ldv<T, V>(own + TW); en_km[2] = ldv<T, V>(own + 2 * TW);
             const size_t rb = ro - sz;
             const int klm = kl - 1, km = k - 1;
             const bool bl_lt = km < Nz, bl_in = km >= 1 && km < Nz;
@@ -326,14 +327,19 @@ __global__ void __launch_bounds__(kLanes * MAXW) __attribute__((amdgpu_waves_per
             }
         }
 
+        // a slab below another one leaves B of its top layer to the kernel that runs once the upper
+        // neighbour's D has arrived; the new buffer only receives the old values here
+        if (a.copy_top && kl == a.kl_stop - 1 && row_ok && !halo_row) {
+            stg<T, V>(ap->Bn[0] + ro, lo, bo[0]); stg<T, V>(ap->Bn[1] + ro, lo, bo[1]); stg<T, V>(ap->Bn[2] + ro, lo, bo[2]);
+        }
+
         // ------------------------------------------------------------ hand-over to the next iteration
         {
-            T* dst = smem + ((size_t)((kl & 1) * W + w) * 2) * TW + lo;
-            stv<T, V>(dst, en[0]); stv<T, V>(dst + TW, en[2]);
+            T* dst = smem + ((size_t)((kl & 1) * W + w) * 3) * TW + lo;
+            stv<T, V>(dst, en[0]); stv<T, V>(dst + TW, en[1]); stv<T, V>(dst + 2 * TW, en[2]);
         }
         hx_km = hx; hy_km = hy; hxe_km = hxe;
         bo_km[0] = bo[0]; bo_km[1] = bo[1]; bo_km[2] = bo[2];
-        en_km[0] = en[0]; en_km[1] = en[1]; en_km[2] = en[2];
         eye_km = eye; eze_km = eze;
         __syncthreads();
     }

@@ -157,14 +157,34 @@ class Engine3D(_Common):
     def half_h(self, part: int = PART_ALL, stream=None) -> None:
         _check(lib().fdtd3d_half_h(self.h, C.c_int(part), _stream_handle(stream)), "fdtd3d_half_h")
 
+    def fused(self, n: int, part: int = PART_ALL, stream=None) -> None:
+        """Both halves of step n in one kernel (MODE_FUSED engines); see fdtd3d_fused in the header."""
+        _check(lib().fdtd3d_fused(self.h, C.c_int(n), C.c_int(part), _stream_handle(stream)), "fdtd3d_fused")
+
+    def fused_top(self, stream=None) -> None:
+        """Finish B of the top owned layer after the upper neighbour's D has arrived (no-op on the last slab)."""
+        _check(lib().fdtd3d_fused_top(self.h, _stream_handle(stream)), "fdtd3d_fused_top")
+
+    def parity(self) -> int:
+        """Which of the two D/B buffer sets is current (changes with every fused step)."""
+        return lib().fdtd3d_buffer_parity(self.h)
+
+    @property
+    def is_fused(self) -> bool:
+        return self.desc.mode == MODE_FUSED
+
     def fill_materials(self, seed, eps_lo, eps_hi, mu_lo, mu_hi) -> None:
         _check(lib().fdtd3d_fill_materials(self.h, C.c_uint64(seed), C.c_double(eps_lo), C.c_double(eps_hi),
                                            C.c_double(mu_lo), C.c_double(mu_hi)), "fdtd3d_fill_materials")
 
-    def halo(self, which: int, comp: int):
-        """(device pointer, bytes) of one ghost-exchange plane."""
+    def halo(self, which: int, comp: int, parity=None):
+        """(device pointer, bytes) of one ghost-exchange plane; `parity` selects the buffer set of a
+        MODE_FUSED engine (default: the current one)."""
         p, n = C.c_void_p(), C.c_size_t()
-        _check(lib().fdtd3d_halo(self.h, C.c_int(which), C.c_int(comp), C.byref(p), C.byref(n)), "fdtd3d_halo")
+        if parity is None:
+            _check(lib().fdtd3d_halo(self.h, C.c_int(which), C.c_int(comp), C.byref(p), C.byref(n)), "fdtd3d_halo")
+        else:
+            _check(lib().fdtd3d_halo_at(self.h, C.c_int(parity), C.c_int(which), C.c_int(comp), C.byref(p), C.byref(n)), "fdtd3d_halo_at")
         return p.value, n.value
 
     def observe_accumulate(self, weight: float, reset: bool, stream=None) -> None:
@@ -224,9 +244,9 @@ class _DeviceSpan:
                                          "data": (ptr, False), "version": 2}
 
 
-def halo_tensor(engine: "Engine3D", which: int, comp: int):
+def halo_tensor(engine: "Engine3D", which: int, comp: int, parity=None):
     """torch tensor aliasing one ghost-exchange plane of the engine (no copy)."""
     import torch
-    ptr, nbytes = engine.halo(which, comp)
+    ptr, nbytes = engine.halo(which, comp, parity)
     itemsize = 4 if engine.precision == 32 else 8
     return torch.as_tensor(_DeviceSpan(ptr, nbytes, itemsize), device=torch.device("cuda", torch.cuda.current_device()))

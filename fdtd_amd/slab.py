@@ -72,6 +72,41 @@ class HaloExchange:
             r.wait()
 
 
+class FusedSlabStepper:
+    """One rank's time loop with the fused whole-step kernel.
+
+    `engine` needs fused(n, part), fused_top() and parity(); `exchanges` holds one HaloExchange per
+    buffer parity (the planes alias whichever D/B buffers are current after the step's first launch).
+    Per step: the lowest chunk of planes first, its D planes start travelling down, the rest of the
+    slab is computed meanwhile; the top layer's B, which needs the upper neighbour's new D, is
+    finished by the single-plane H kernel once that plane has arrived, and then travels up for the
+    next step's lowest chunk.
+    """
+
+    def __init__(self, engine, exchanges: Sequence[HaloExchange], stream=None):
+        self.engine, self.xs, self.stream = engine, list(exchanges), stream
+        self._pending_b: list = []
+
+    def step(self, n: int) -> None:
+        e, s = self.engine, self.stream
+        HaloExchange.wait(self._pending_b)           # B of layer z_lo-1, for the lowest chunk
+        e.fused(n, PART_EDGE, s)
+        x = self.xs[e.parity() % len(self.xs)]
+        pending_d = x.start_down()
+        e.fused(n, PART_INTERIOR, s)
+        HaloExchange.wait(pending_d)                 # new D of layer z_hi
+        e.fused_top(s)
+        self._pending_b = x.start_up()
+
+    def run(self, n0: int, count: int) -> None:
+        for n in range(n0, n0 + count):
+            self.step(n)
+
+    def finish(self) -> None:
+        HaloExchange.wait(self._pending_b)
+        self._pending_b = []
+
+
 class SlabStepper:
     """One rank's time loop.  `engine` needs half_e(n, part), half_h(part); `exchange` a HaloExchange."""
 
@@ -102,9 +137,15 @@ class SlabStepper:
         self._pending_h = []
 
 
-def make_gpu_stepper(engine, rank: int, world: int, group=None, stream=None) -> SlabStepper:
-    """Wire an Engine3D's own ghost planes into a SlabStepper (tensors alias engine memory)."""
+def make_gpu_stepper(engine, rank: int, world: int, group=None, stream=None):
+    """Wire an Engine3D's own ghost planes into a stepper (tensors alias engine memory): a
+    FusedSlabStepper for MODE_FUSED engines, a SlabStepper otherwise."""
     from .engine import HALO_RECV_HI, HALO_RECV_LO, HALO_SEND_DOWN, HALO_SEND_UP, halo_tensor
-    planes = {w: [halo_tensor(engine, w, c) for c in (0, 1)] for w in (HALO_SEND_UP, HALO_RECV_LO, HALO_SEND_DOWN, HALO_RECV_HI)}
-    x = HaloExchange(rank, world, planes[HALO_SEND_UP], planes[HALO_RECV_LO], planes[HALO_SEND_DOWN], planes[HALO_RECV_HI], group)
-    return SlabStepper(engine, x, stream)
+
+    def exchange(parity=None):
+        planes = {w: [halo_tensor(engine, w, c, parity) for c in (0, 1)] for w in (HALO_SEND_UP, HALO_RECV_LO, HALO_SEND_DOWN, HALO_RECV_HI)}
+        return HaloExchange(rank, world, planes[HALO_SEND_UP], planes[HALO_RECV_LO], planes[HALO_SEND_DOWN], planes[HALO_RECV_HI], group)
+
+    if not getattr(engine, "is_fused", False):
+        return SlabStepper(engine, exchange(), stream)
+    return FusedSlabStepper(engine, [exchange(0), exchange(1)], stream)

@@ -70,8 +70,8 @@ enum {
 /* Storage modes. */
 #define FDTD3D_MODE_FULL 0   /* D,E,B,H all resident (the reference's formulation)            */
 #define FDTD3D_MODE_LEAN 1   /* only D,B resident; E=D/eps, H=B/mu recomputed where consumed */
-#define FDTD3D_MODE_FUSED 2  /* lean storage with D, B ping-pong buffers; fdtd3d_step runs one
-                                kernel per time step (whole grid on one device only)          */
+#define FDTD3D_MODE_FUSED 2  /* lean storage plus second D, B and D-side CPML buffers: one kernel
+                                per time step (fdtd3d_step / fdtd3d_fused), both halves fused */
 
 typedef struct fdtd3d_desc {
     int32_t struct_size;      /* sizeof(fdtd3d_desc), for forward compatibility             */
@@ -124,6 +124,21 @@ int fdtd3d_step(fdtd3d_handle h, int n0, int count, void* stream);
 int fdtd3d_half_e(fdtd3d_handle h, int n, int part, void* stream);
 int fdtd3d_half_h(fdtd3d_handle h, int part, void* stream);
 
+/* FUSED mode: both halves of step n in one kernel (updateE then updateH of FDTD3D.cpp:480-1021,
+ * cell for cell in the same operation order), reading the current D, B and D-side CPML buffers
+ * and writing the other set; the two sets change roles when the first part of a step is launched.
+ *   PART_ALL       the whole slab.
+ *   PART_EDGE      the lowest planes (one chunk, see fdtd3d_tune), so that D of layer z_lo can
+ *                  travel down while PART_INTERIOR, which must follow, computes the rest.
+ * A slab below another one leaves B of its top layer z_hi-1 unchanged: once the upper
+ * neighbour's D has arrived in the high ghost plane, fdtd3d_fused_top() finishes it with the
+ * single-plane H kernel (a no-op on the slab that holds k = Nz).
+ * fdtd3d_halo() always refers to the current buffers (fdtd3d_buffer_parity() tells which set,
+ * 0 or 1, that is), so pointers must be fetched again after a step or cached per parity. */
+int fdtd3d_fused(fdtd3d_handle h, int n, int part, void* stream);
+int fdtd3d_fused_top(fdtd3d_handle h, void* stream);
+int fdtd3d_buffer_parity(fdtd3d_handle h);
+
 /* Ghost-plane exchange buffers (device pointers into the engine's own arrays; each is
  * one contiguous x-y plane of `bytes` bytes).  which: */
 #define FDTD3D_HALO_SEND_UP 0    /* tangential H (FULL) / B (LEAN), top owned layer -> rank+1 */
@@ -132,6 +147,8 @@ int fdtd3d_half_h(fdtd3d_handle h, int part, void* stream);
 #define FDTD3D_HALO_RECV_HI 3    /* ghost layer z_hi                               <- rank+1 */
 /* comp 0 = x component, 1 = y component. */
 int fdtd3d_halo(fdtd3d_handle h, int which, int comp, void** dev_ptr, size_t* bytes);
+/* The same for buffer set `parity` (0 or 1) of a FUSED engine, whichever is current. */
+int fdtd3d_halo_at(fdtd3d_handle h, int parity, int which, int comp, void** dev_ptr, size_t* bytes);
 
 /* Sum over owned cells of the squares of array `id`, accumulated in double on device
  * (diagnostic / checksum). */
@@ -158,14 +175,15 @@ int fdtd3d_observe_frame(fdtd3d_handle h, double* ex_center, double* e_mag, size
 size_t fdtd3d_device_bytes(fdtd3d_handle h);
 
 /* Launch-shape knobs (no effect on results): planes marched per workgroup (1..4096), XCD-contiguous
- * tile order (0/1), rows (= waves) per workgroup (1..4); a value outside its range keeps the
- * current setting.  The environment variables FDTD_Z_CHUNK / FDTD_XCD_REMAP / FDTD_ROWS_PER_GROUP
+ * tile order (0/1), rows (= waves) per workgroup (1..4 for the half-step kernels; 2..16 for the
+ * fused kernel, whose last wave recomputes the first row of the next tile); a value outside its
+ * range keeps the current setting.  The environment variables FDTD_Z_CHUNK / FDTD_XCD_REMAP / FDTD_ROWS_PER_GROUP
  * set them at creation. */
 int fdtd3d_tune(fdtd3d_handle h, int chunk, int remap, int rows);
 
 /* Timing hook for the dominant kernels: if enabled, every E-half / H-half launch is
  * bracketed by HIP events on its stream; fdtd3d_kernel_time() synchronises and returns
- * the launch count and the summed device time (ms) per kernel kind (0 = E, 1 = H). */
+ * the launch count and the summed device time (ms) per kernel kind (0 = E, 1 = H, 2 = fused). */
 int fdtd3d_kernel_timing(fdtd3d_handle h, int enable);
 int fdtd3d_kernel_time(fdtd3d_handle h, int kind, int* launches, double* total_ms);
 

@@ -93,7 +93,67 @@ def test_fused_ragged_shapes_3d(prec, N, npml, rows, chunk):
             util.assert_equal_arrays(eng.get(id_), tw.get(id_), f"N={N} array {id_}")
 
 
-def test_fused_needs_whole_grid():
+def run_fused_slabs(meta, ins, parts, prec, steps, chunk, has_mu=False, extra_feed=None):
+    """Several FUSED slab engines in one process; ghost planes move by device copies exactly where
+    the send/recv pairs sit in fdtd_amd.slab.FusedSlabStepper."""
+    from fdtd_amd import engine as E
+    engs = [fdtd_amd.Engine3D(meta["N"], meta["npml"], (meta["dx"], meta["dy"], meta["dz"]), meta["dt"], meta["mu0"],
+                              meta["k_Jx"], meta["steps"], precision=prec, mode=MODE_FUSED, z_range=p, has_mu=has_mu) for p in parts]
+    for e in engs:
+        e.tune(chunk, 1, 0)
+        util.feed(e, ins)
+        if extra_feed:
+            extra_feed(e)
+    pl = [[{w: [E.halo_tensor(e, w, c, par) for c in (0, 1)] for w in range(4)} for par in (0, 1)] for e in engs]
+    for n in range(steps):
+        for e in engs:
+            e.fused(n, E.PART_EDGE)
+        cur = [pl[r][engs[r].parity()] for r in range(len(engs))]
+        for r in range(1, len(engs)):
+            for c in (0, 1):
+                cur[r - 1][E.HALO_RECV_HI][c].copy_(cur[r][E.HALO_SEND_DOWN][c])
+        for e in engs:
+            e.fused(n, E.PART_INTERIOR)
+        for e in engs:
+            e.fused_top()
+        for r in range(len(engs) - 1):
+            for c in (0, 1):
+                cur[r + 1][E.HALO_RECV_LO][c].copy_(cur[r][E.HALO_SEND_UP][c])
+    return engs
+
+
+@pytest.mark.parametrize("name,world,chunk", [("g1_3d_cpml", 2, 8), ("g3_3d_hetero", 3, 2), ("g2_3d_cavity", 4, 3), ("g3_3d_hetero", 8, 16)])
+def test_fused_slabs_reproduce_reference(name, world, chunk):
+    from fdtd_amd import slab
+    from tests.test_gpu_slabs import assemble
+    meta, ins, outs, _ = util.load_fixture(name)
+    steps = meta["steps"]
+    engs = run_fused_slabs(meta, ins, slab.partition(meta["N"][2], world), 64, steps, chunk)
+    for (step, id_), want in outs.items():
+        if step == steps:
+            util.assert_equal_arrays(assemble(engs, id_), want, f"{name} x{world} fused slabs, array {id_}")
+
+
+def test_fused_slabs_fp32_mu_grid_equal_whole_grid():
+    from tests.test_gpu_slabs import assemble
+    meta, ins, outs, _ = util.load_fixture("g3_3d_hetero")
+    K = meta
+    fill = lambda e: e.fill_materials(5, K["eps0"], 3 * K["eps0"], K["mu0"], 2 * K["mu0"])
+    whole = run_fused_slabs(meta, ins, [(0, meta["N"][2])], 32, 31, 4, has_mu=True, extra_feed=fill)
+    parts = run_fused_slabs(meta, ins, [(0, 5), (5, 6), (6, 19), (19, 26)], 32, 31, 4, has_mu=True, extra_feed=fill)
+    for id_ in po.FIELDS3D + po.ALL_PHI3D:
+        util.assert_equal_arrays(assemble(parts, id_), assemble(whole, id_), f"uneven fused slabs, array {id_}")
+
+
+def test_fused_part_order_is_checked():
     K = po.consts()
-    with pytest.raises(Exception):
-        fdtd_amd.Engine3D((16, 16, 16), (0,) * 6, (1e-7,) * 3, 1e-16, K["mu0"], 4, 3, precision=32, mode=MODE_FUSED, z_lo=0, z_hi=8)
+    eng = fdtd_amd.Engine3D((16, 16, 16), (0,) * 6, (1e-7,) * 3, 1e-16, K["mu0"], 4, 3, precision=32, mode=MODE_FUSED, z_range=(0, 8))
+    with pytest.raises(fdtd_amd.engine.EngineError):
+        eng.fused(0, fdtd_amd.engine.PART_INTERIOR)
+    eng.fused(0, fdtd_amd.engine.PART_EDGE)
+    with pytest.raises(fdtd_amd.engine.EngineError):
+        eng.fused(0, fdtd_amd.engine.PART_EDGE)
+    eng.fused(0, fdtd_amd.engine.PART_INTERIOR)
+    lean = fdtd_amd.Engine3D((16, 16, 16), (0,) * 6, (1e-7,) * 3, 1e-16, K["mu0"], 4, 3, precision=32, mode=fdtd_amd.engine.MODE_LEAN)
+    with pytest.raises(fdtd_amd.engine.EngineError):
+        lean.fused(0)

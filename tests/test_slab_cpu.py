@@ -63,6 +63,79 @@ class Line:
                 self.H[kl] = self.H[kl] + 0.5 * (self.E[kl + 1] - self.E[kl])
 
 
+class FusedLine(Line):
+    """The same line with the fused engine's contract: two buffer sets, fused(n, part) that computes
+    E_new(k) and, one plane behind, H_new(k-1) chunk by chunk (a chunk recomputes E_new of the plane
+    that closes it), the top layer's H left to half_h(PART_EDGE) on a slab below another one."""
+    chunk = 4
+
+    def __init__(self, Nz, z_lo, z_hi, kJ):
+        super().__init__(Nz, z_lo, z_hi, kJ)
+        self.bufs = [(self.E, self.H), (torch.zeros_like(self.E), torch.zeros_like(self.H))]
+        self.cur, self.mid = 0, False
+
+    def parity(self):
+        return self.cur
+
+    def fused_top(self, stream=None):
+        if not self.last:
+            self.half_h(slab.PART_EDGE)
+
+    def _e_new(self, n, kl, Eo, Ho):
+        k = self.z_lo - 1 + kl
+        v = Eo[kl].clone()
+        if 1 <= k < self.Nz:
+            v = v + 0.5 * (Ho[kl] - Ho[kl - 1])
+        if k == self.kJ:
+            v = v + np.sin(0.3 * (n + 1))
+        return v
+
+    def fused(self, n, part, stream=None):
+        lo, hi = 1, (self.nzl + 2 if self.last else self.nzl + 1)
+        cut = min(lo + self.chunk, hi)
+        kl0, kl1 = {slab.PART_ALL: (lo, hi), slab.PART_EDGE: (lo, cut), slab.PART_INTERIOR: (cut, hi)}[part]
+        assert (part == slab.PART_INTERIOR) == self.mid
+        old, new = (1 - self.cur, self.cur) if self.mid else (self.cur, 1 - self.cur)
+        (Eo, Ho), (En, Hn) = self.bufs[old], self.bufs[new]
+        for cb in range(kl0, kl1, self.chunk):
+            ce = min(cb + self.chunk, kl1)
+            end = ce + 1 if ce < hi else ce
+            e_prev = None
+            for kl in range(cb, end):
+                e = self._e_new(n, kl, Eo, Ho)
+                if kl < ce:
+                    En[kl] = e
+                if kl > cb and self.z_lo - 1 + (kl - 1) < self.Nz:
+                    Hn[kl - 1] = Ho[kl - 1] + 0.5 * (e - e_prev)
+                e_prev = e
+                if not self.last and kl == hi - 1:
+                    Hn[kl] = Ho[kl]
+        if part != slab.PART_INTERIOR:
+            self.cur = 1 - self.cur
+            self.E, self.H = self.bufs[self.cur]
+        self.mid = part == slab.PART_EDGE
+
+
+def _fused_worker(rank, world, port, Nz, steps, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z_lo, z_hi = slab.partition(Nz, world)[rank]
+    eng = FusedLine(Nz, z_lo, z_hi, kJ=3)
+    xs = [slab.HaloExchange(rank, world, [H[eng.nzl:eng.nzl + 1]], [H[0:1]], [E[1:2]], [E[eng.nzl + 1:eng.nzl + 2]]) for E, H in eng.bufs]
+    st = slab.FusedSlabStepper(eng, xs)
+    st.run(0, steps)
+    st.finish()
+    owned_e = eng.E[1:eng.nzl + 1 + (1 if eng.last else 0)].clone()
+    owned_h = eng.H[1:eng.nzl + 1].clone()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (owned_e.numpy(), owned_h.numpy()))
+    if rank == 0:
+        np.save(out + "_e.npy", np.concatenate([g[0] for g in gathered]))
+        np.save(out + "_h.npy", np.concatenate([g[1] for g in gathered]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _worker(rank, world, port, Nz, steps, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -98,6 +171,32 @@ def test_two_rank_exchange_reproduces_single_rank(tmp_path, world):
         ref.half_h(slab.PART_ALL)
     out = str(tmp_path / "slab")
     mp.spawn(_worker, args=(world, _free_port(), Nz, steps, out), nprocs=world, join=True)
+    e, h = np.load(out + "_e.npy"), np.load(out + "_h.npy")
+    assert np.array_equal(e, ref.E[1:Nz + 2].numpy())
+    assert np.array_equal(h, ref.H[1:Nz + 1].numpy())
+    assert np.abs(e).max() > 0.1
+
+
+def test_fused_line_equals_half_steps():
+    """The stand-in's fused step is the same arithmetic as its two half steps (single rank)."""
+    Nz, steps = 23, 41
+    ref, fl = Line(Nz, 0, Nz, kJ=3), FusedLine(Nz, 0, Nz, kJ=3)
+    for n in range(steps):
+        ref.half_e(n, slab.PART_ALL)
+        ref.half_h(slab.PART_ALL)
+        fl.fused(n, slab.PART_ALL)
+    assert torch.equal(fl.E, ref.E) and torch.equal(fl.H, ref.H)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_fused_exchange_reproduces_single_rank(tmp_path, world):
+    Nz, steps = 23, 41
+    ref = Line(Nz, 0, Nz, kJ=3)
+    for n in range(steps):
+        ref.half_e(n, slab.PART_ALL)
+        ref.half_h(slab.PART_ALL)
+    out = str(tmp_path / "fslab")
+    mp.spawn(_fused_worker, args=(world, _free_port(), Nz, steps, out), nprocs=world, join=True)
     e, h = np.load(out + "_e.npy"), np.load(out + "_h.npy")
     assert np.array_equal(e, ref.E[1:Nz + 2].numpy())
     assert np.array_equal(h, ref.H[1:Nz + 1].numpy())
