@@ -6,15 +6,17 @@
 
 Workload (BASELINE.json config 4/5): 1024 x 1024 x (1024 * N) cells, heterogeneous eps and mu
 grids (synthetic, counter hash), 20-layer CPML on all six faces, Gaussian sheet current source,
-fp32, one z-slab of 1024 layers per GPU, one ghost plane of tangential E and H exchanged per half
-step.  One "step" = E-half + H-half over the whole grid.  All inputs are generated on the device
-before the timed region.  Prints ONE JSON line (rank 0).
+fp32, one z-slab of 1024 layers per GPU, one ghost plane of tangential D (E) and B (H) exchanged
+per step half.  One "step" = E-half + H-half over the whole grid, by default in ONE fused kernel per
+step (plus, on a slab below another one, the single-plane H kernel that finishes its top layer).
+All inputs are generated on the device before the timed region.  Prints ONE JSON line (rank 0).
 
 Environment knobs for experiments (the defaults are the graded configuration):
   FDTD_BENCH_N=512       edge length per GPU instead of 1024
   FDTD_BENCH_MU=0        constant mu0 instead of a mu grid
   FDTD_BENCH_CPU=0       skip the CPU baseline leg
-  FDTD_BENCH_MODE=full   keep E and H resident (the reference's storage) instead of the lean default
+  FDTD_BENCH_MODE=lean   two half-step kernels over D,B-only storage instead of the fused default
+  FDTD_BENCH_MODE=full   two half-step kernels, E and H resident too (the reference's storage)
 """
 import argparse
 import json
@@ -93,7 +95,10 @@ def main():
 
     n_edge = int(os.environ.get("FDTD_BENCH_N", "1024"))
     has_mu = os.environ.get("FDTD_BENCH_MU", "1") != "0"
-    lean = os.environ.get("FDTD_BENCH_MODE", "lean") != "full"
+    mode_name = os.environ.get("FDTD_BENCH_MODE", "fused")
+    if mode_name not in ("fused", "lean", "full"):
+        raise SystemExit(f"FDTD_BENCH_MODE={mode_name}: expected fused, lean or full")
+    lean = mode_name == "lean"
     Nx = Ny = n_edge
     Nz = n_edge * world
     npml = (20,) * 6
@@ -104,7 +109,7 @@ def main():
     z_lo, z_hi = slab.partition(Nz, world)[rank]
 
     eng = fdtd_amd.Engine3D((Nx, Ny, Nz), npml, d, dt, K["mu0"], 20, n_total, precision=32, has_mu=has_mu,
-                            mode=fdtd_amd.engine.MODE_LEAN if lean else fdtd_amd.engine.MODE_FULL,
+                            mode={"fused": fdtd_amd.engine.MODE_FUSED, "lean": fdtd_amd.engine.MODE_LEAN, "full": fdtd_amd.engine.MODE_FULL}[mode_name],
                             z_range=(z_lo, z_hi), device=local)
     fs.load_cpml3d(eng, d, dt)
     wf, mag = fs.default_source3d(Nx, Ny, n_total, d, dt)
@@ -145,16 +150,22 @@ def main():
     # per-kernel device time from HIP events recorded on the launch stream
     n_e, ms_e = eng.kernel_time(0)
     n_h, ms_h = eng.kernel_time(1)
+    n_f, ms_f = eng.kernel_time(2)
     cells_local = Nx * Ny * (z_hi - z_lo)
-    # algorithmic bytes per cell per launch, fp32: E-half reads H(3) + r/w D(6) + eps(3) + writes E(3) = 15 words;
-    # H-half reads E(3) + r/w B(6) + writes H(3) = 12 words, +3 for the mu grid
+    # algorithmic bytes per cell, fp32, in the reference's formulation whatever the kernels really move:
+    # E-half reads H(3) + r/w D(6) + eps(3) + writes E(3) = 15 words; H-half reads E(3) + r/w B(6) + writes
+    # H(3) = 12 words, +3 for the mu grid.  A fused launch does both halves of its cells.
     bytes_e, bytes_h = 15 * 4, (12 + (3 if has_mu else 0)) * 4
-    launches_per_step_e = max(n_e // max(args.steps, 1), 1)
-    launches_per_step_h = max(n_h // max(args.steps, 1), 1)
-    t_e = ms_e / max(args.steps, 1) * 1e-3          # device seconds per step spent in E-half kernels
-    t_h = ms_h / max(args.steps, 1) * 1e-3
-    dom = "k3_half_e" if t_e >= t_h else "k3_half_h"
-    ach = (cells_local * (bytes_e if dom == "k3_half_e" else bytes_h)) / (t_e if dom == "k3_half_e" else t_h) / 1e9
+    steps_ = max(args.steps, 1)
+    t_e, t_h, t_f = ms_e / steps_ * 1e-3, ms_h / steps_ * 1e-3, ms_f / steps_ * 1e-3   # device seconds per step per kernel kind
+    if mode_name == "fused":
+        # per step the fused launches (one, or lowest chunk + rest on a slab) together visit every owned cell once
+        dom, dom_bytes, t_dom = "k3_fused", bytes_e + bytes_h, t_f
+    elif t_e >= t_h:
+        dom, dom_bytes, t_dom = "k3_half_e", bytes_e, t_e
+    else:
+        dom, dom_bytes, t_dom = "k3_half_h", bytes_h, t_h
+    ach = cells_local * dom_bytes / t_dom / 1e9
     sums = [eng.sumsq(i) for i in (fdtd_amd.engine.DX, fdtd_amd.engine.BY)]
     finite = all(v == v and v < float("inf") for v in sums)
     ex_energy = sums[0]
@@ -163,9 +174,9 @@ def main():
     # read from inside this process); only reported when this run is the configuration they were taken on
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_traffic_1024_lean.json")) as f:
+        with open(os.path.join(ROOT, "profiles", f"r1_traffic_1024_{mode_name}.json")) as f:
             rec = json.load(f)
-        if lean and has_mu and n_edge == 1024 and cells_local == 1024 ** 3:
+        if has_mu and n_edge == 1024 and world == 1:
             traffic = rec["per_launch"][dom]["total_bytes"]
     except (OSError, KeyError, ValueError):
         traffic = None
@@ -181,14 +192,17 @@ def main():
             "config": {"workload": f"fdtd3d {Nx}x{Ny}x{Nz} ({Nz // world} layers per GPU), heterogeneous eps"
                                    f"{'/mu' if has_mu else ''} grid, 20-layer CPML on six faces, Gaussian sheet source",
                        "grid": [Nx, Ny, Nz], "cpml_layers": 20, "mu_grid": has_mu, "decomposition": f"z-slabs x{world}",
-                       "storage": "D,B resident; E=D/eps, H=B/mu recomputed in the consuming kernel" if lean else "D,E,B,H resident", "device_bytes_per_gpu": eng.device_bytes()},
+                       "storage": {"fused": "D,B resident in two buffer sets; E=D/eps, H=B/mu formed in registers; one kernel per step",
+                                   "lean": "D,B resident; E=D/eps, H=B/mu recomputed in the consuming kernel; two kernels per step",
+                                   "full": "D,E,B,H resident; two kernels per step"}[mode_name],
+                       "device_bytes_per_gpu": eng.device_bytes()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": cells_local * (bytes_e if dom == "k3_half_e" else bytes_h),
-                         "algorithmic_bytes_per_cell": bytes_e if dom == "k3_half_e" else bytes_h,
+                         "algorithmic_bytes_per_launch": cells_local * dom_bytes,
+                         "algorithmic_bytes_per_cell": dom_bytes,
                          "cells_per_launch": cells_local,
-                         "ms_per_step_e_half": t_e * 1e3, "ms_per_step_h_half": t_h * 1e3,
-                         "launches_per_step": [launches_per_step_e, launches_per_step_h],
+                         "ms_per_step_e_half": t_e * 1e3, "ms_per_step_h_half": t_h * 1e3, "ms_per_step_fused": t_f * 1e3,
+                         "launches_per_step": {"k3_half_e": n_e / steps_, "k3_half_h": n_h / steps_, "k3_fused": n_f / steps_},
                          "whole_step_frac": (cells_local * world * bytes_step * args.steps / el / 1e9) / (HBM_PEAK_GBS * world)},
             "checks": {"finite": bool(finite), "sumsq_dx_rank0": ex_energy},
         }

@@ -19,13 +19,14 @@ struct Sim3DConfig {
     int k_Jx;
     int precision;         // 64 reproduces the reference's files byte for byte; 32 is the fast path
     bool lean;             // keep only D and B on the device
+    bool fused;            // one kernel per time step (implies lean storage, two buffer sets)
     int n_T0;              // steps per optical period: RMS window = n_T0/2, weights 4/n_T0
     int frame_every;
     bool write_files;
     std::string out_dir;
     // The reference's hard-coded problem (FDTD3D.cpp:21-39, :71, FDTD3D.h:54-56).
     static Sim3DConfig reference_default();
-    // Overrides from FDTD3D_NX / _NY / _NZ / _STEPS / _NPML / _KJX / _PRECISION / _LEAN / _FRAME_EVERY /
+    // Overrides from FDTD3D_NX / _NY / _NZ / _STEPS / _NPML / _KJX / _PRECISION / _LEAN / _FUSED / _FRAME_EVERY /
     // _WRITE / _OUT environment variables (the reference's main() takes no arguments).
     void apply_environment();
 };

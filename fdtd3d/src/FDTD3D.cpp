@@ -42,6 +42,7 @@ Sim3DConfig Sim3DConfig::reference_default() {
     c.k_Jx = 20;
     c.precision = 64;
     c.lean = true;
+    c.fused = true;
     c.n_T0 = static_cast<int>(std::round(2 * cells_per_wavelength));
     c.frame_every = 20;
     c.write_files = true;
@@ -56,6 +57,7 @@ void Sim3DConfig::apply_environment() {
     int v;
     if (env_int("FDTD3D_NPML", v)) for (int& n : n_pml) n = v;
     if (env_int("FDTD3D_LEAN", v)) lean = v != 0;
+    if (env_int("FDTD3D_FUSED", v)) fused = v != 0;
     if (env_int("FDTD3D_WRITE", v)) write_files = v != 0;
     if (const char* e = std::getenv("FDTD3D_OUT")) if (*e) out_dir = e;
 }
@@ -80,7 +82,7 @@ void FDTD3D::build() {
     d.Nx = c.Nx; d.Ny = c.Ny; d.Nz = c.Nz;
     for (int q = 0; q < 6; ++q) d.n_pml[q] = c.n_pml[q];
     d.k_Jx = c.k_Jx; d.n_wf = c.steps; d.precision = c.precision; d.has_mu = 0;
-    d.mode = c.lean ? FDTD3D_MODE_LEAN : FDTD3D_MODE_FULL;
+    d.mode = c.fused ? FDTD3D_MODE_FUSED : (c.lean ? FDTD3D_MODE_LEAN : FDTD3D_MODE_FULL);
     d.z_lo = 0; d.z_hi = c.Nz; d.device = -1;
     d.dx = c.dx; d.dy = c.dy; d.dz = c.dz; d.dt = c.dt; d.mu0 = mu0;
     must(fdtd3d_create(&d, &m_engine), "fdtd3d_create");

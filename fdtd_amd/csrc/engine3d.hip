@@ -167,12 +167,63 @@ struct Engine3 : fdtd3d_engine {
         timer.release();
     }
 
+    // All arrays of the time loop are carved from one device allocation.  Consecutive arrays start
+    // `skew` bytes further into the 4 KB granule than their predecessor, so that the dozen-odd streams
+    // a kernel reads at the same (row, plane) position do not all sit at the same phase of the memory
+    // channel interleave.  `planning` sums the sizes first.
+    char* arena = nullptr;
+    size_t arena_cap = 0, arena_used = 0, skew = 0;
+    int n_carved = 0;
+    bool planning = false;
+    static constexpr size_t kGranule = 4096;
     int dalloc(void** p, size_t nbytes, int fill_byte_pattern_zero = 1) {
         if (nbytes == 0) { *p = nullptr; return FDTD_OK; }
-        FDTD_HIP(hipMalloc(p, nbytes));
-        allocs.push_back(*p);
-        bytes += nbytes;
+        const size_t lead = ((size_t)n_carved * skew) % kGranule;
+        const size_t span = (lead + nbytes + kGranule - 1) / kGranule * kGranule;
+        ++n_carved;
+        if (planning) { arena_used += span; *p = nullptr; return FDTD_OK; }
+        if (arena && arena_used + span <= arena_cap) {
+            *p = arena + arena_used + lead;
+            arena_used += span;
+            bytes += nbytes;
+        } else {                            // arrays created after set-up (observables) stand alone
+            FDTD_HIP(hipMalloc(p, nbytes));
+            allocs.push_back(*p);
+            bytes += nbytes;
+        }
         if (fill_byte_pattern_zero) FDTD_HIP(hipMemset(*p, 0, nbytes));
+        return FDTD_OK;
+    }
+
+    int allocate_all() {
+        int rc;
+        for (int f = 0; f < 6; ++f) for (int c = 0; c < 3; ++c) {
+            const int id = f * 3 + c;
+            fld[id] = nullptr;
+            if (f == 5 && !d.has_mu) continue;
+            if (!full && (f == 1 || f == 3)) continue;
+            // one row of slack behind every array: vector accesses of the last row may look one pack ahead
+            if ((rc = dalloc((void**)&fld[id], (fsize + px) * sizeof(T)))) return rc;
+            if (f >= 4 && !planning) { if ((rc = fill_const(fld[id], fsize + px, (T)1))) return rc; }
+            if (fused && (f == 0 || f == 2)) { if ((rc = dalloc((void**)&alt[id], (fsize + px) * sizeof(T)))) return rc; }
+        }
+        for (int m = 0; m < 2; ++m) for (int c = 0; c < 3; ++c) for (int a = 0; a < 3; ++a) for (int s = 0; s < 2; ++s) {
+            T** slot = m ? &phM[c][a][s] : &phE[c][a][s];
+            *slot = nullptr;
+            phSize[m][c][a][s] = 0;
+            if (a == c || np[a][s] == 0) continue;
+            size_t n = 0;
+            if (a == 2) n = (size_t)np[2][s] * plane;
+            else if (a == 1) n = (size_t)nzp * np[1][s] * px;
+            else n = (size_t)nzp * ny1 * (s ? xwp : xwn);
+            phSize[m][c][a][s] = n;
+            if ((rc = dalloc((void**)slot, (n + px) * sizeof(T)))) return rc;
+            if (!m) { phE2[c][a][s] = nullptr; if (fused && (rc = dalloc((void**)&phE2[c][a][s], (n + px) * sizeof(T)))) return rc; }
+        }
+        if ((rc = dalloc((void**)&tab_d, (size_t)3 * 2 * 6 * kMaxLayers * sizeof(T)))) return rc;
+        if ((rc = dalloc((void**)&xrow_d, (size_t)6 * px * sizeof(T)))) return rc;
+        if ((rc = dalloc((void**)&mag_d, plane * sizeof(T)))) return rc;
+        if ((rc = dalloc((void**)&red_d, 1025 * sizeof(double)))) return rc;
         return FDTD_OK;
     }
 
@@ -198,35 +249,16 @@ struct Engine3 : fdtd3d_engine {
         if (const char* e = getenv("FDTD_FUSED_VEC")) { int v = atoi(e); if (v == V || v == V / 2) fvec = v; }
         if (const char* e = getenv("FDTD_ROWS_PER_GROUP")) { int w = atoi(e); if (w >= 1 && w <= 4) wpb = w; }
 
+        if (const char* e = getenv("FDTD_ARRAY_SKEW")) { long v = atol(e); if (v >= 0 && v % 256 == 0) skew = (size_t)v; }
         int rc;
-        for (int f = 0; f < 6; ++f) for (int c = 0; c < 3; ++c) {
-            const int id = f * 3 + c;
-            fld[id] = nullptr;
-            if (f == 5 && !d.has_mu) continue;
-            if (!full && (f == 1 || f == 3)) continue;
-            // one row of slack behind every array: vector accesses of the last row may look one pack ahead
-            if ((rc = dalloc((void**)&fld[id], (fsize + px) * sizeof(T)))) return rc;
-            if (f >= 4) { if ((rc = fill_const(fld[id], fsize + px, (T)1))) return rc; }
-            if (fused && (f == 0 || f == 2)) { if ((rc = dalloc((void**)&alt[id], (fsize + px) * sizeof(T)))) return rc; }
-        }
-        for (int m = 0; m < 2; ++m) for (int c = 0; c < 3; ++c) for (int a = 0; a < 3; ++a) for (int s = 0; s < 2; ++s) {
-            T** slot = m ? &phM[c][a][s] : &phE[c][a][s];
-            *slot = nullptr;
-            phSize[m][c][a][s] = 0;
-            if (a == c || np[a][s] == 0) continue;
-            size_t n = 0;
-            if (a == 2) n = (size_t)np[2][s] * plane;
-            else if (a == 1) n = (size_t)nzp * np[1][s] * px;
-            else n = (size_t)nzp * ny1 * (s ? xwp : xwn);
-            phSize[m][c][a][s] = n;
-            if ((rc = dalloc((void**)slot, (n + px) * sizeof(T)))) return rc;
-            if (!m) { phE2[c][a][s] = nullptr; if (fused && (rc = dalloc((void**)&phE2[c][a][s], (n + px) * sizeof(T)))) return rc; }
-        }
+        planning = true; arena_used = 0; n_carved = 0;
+        if ((rc = allocate_all())) return rc;
+        planning = false;
+        arena_cap = arena_used; arena_used = 0; n_carved = 0;
+        FDTD_HIP(hipMalloc((void**)&arena, arena_cap));
+        allocs.push_back(arena);
+        if ((rc = allocate_all())) return rc;
         tab_h.assign((size_t)3 * 2 * 6 * kMaxLayers, 0.0);
-        if ((rc = dalloc((void**)&tab_d, tab_h.size() * sizeof(T)))) return rc;
-        if ((rc = dalloc((void**)&xrow_d, (size_t)6 * px * sizeof(T)))) return rc;
-        if ((rc = dalloc((void**)&mag_d, plane * sizeof(T)))) return rc;
-        if ((rc = dalloc((void**)&red_d, 1025 * sizeof(double)))) return rc;
         wf.assign(d.n_wf > 0 ? d.n_wf : 0, (T)0);
         return upload_tables();
     }

@@ -92,3 +92,50 @@ def test_energy_growth_heuristic_1024_plane_source():
     e2 = eng.sumsq(E.DX)
     assert np.isfinite(e1) and np.isfinite(e2) and e1 > 0
     assert 0.1 < e2 / e1 < 100
+
+
+def test_fused_equals_lean_1024_headline_workload():
+    """The benchmarked configuration itself (1024^3, eps/mu grids, 20-layer CPML, fp32): the fused
+    whole-step kernel and the two half-step kernels must leave identical bits in D and B after an odd
+    number of steps (so that the comparison reads the second buffer set), for two launch shapes."""
+    N, steps = (1024, 1024, 1024), 7
+    lean = make(N, (20,) * 6, E.MODE_LEAN, True, steps=steps)
+    lean.step(0, steps)
+    want = [lean.checksum(i) for i in FIELDS]
+    e_lean = lean.sumsq(E.DX)
+    lean.close()
+    assert e_lean > 0 and np.isfinite(e_lean)
+    fused = make(N, (20,) * 6, E.MODE_FUSED, True, steps=steps)
+    fused.step(0, 4)
+    fused.tune(5, 0, 8)
+    fused.step(4, steps - 4)
+    assert [fused.checksum(i) for i in FIELDS] == want
+    fused.close()
+
+
+def test_fused_slabs_equal_whole_grid_384():
+    """Fused stepping on 4 slabs (lowest chunk first, top layer finished after the exchange) == the
+    half-step kernels on the whole grid, eps/mu grids and 20-layer CPML."""
+    N, steps = (384, 384, 512), 11
+    whole = make(N, (20,) * 6, E.MODE_LEAN, True, steps=steps)
+    whole.step(0, steps)
+    want = [whole.checksum(i) for i in FIELDS]
+    whole.close()
+    parts = slab.partition(N[2], 4)
+    engs = [make(N, (20,) * 6, E.MODE_FUSED, True, z_range=p, steps=steps) for p in parts]
+    pl = [[{w: [E.halo_tensor(e, w, c, par) for c in (0, 1)] for w in range(4)} for par in (0, 1)] for e in engs]
+    for n in range(steps):
+        for e in engs:
+            e.fused(n, E.PART_EDGE)
+        cur = [pl[r][engs[r].parity()] for r in range(4)]
+        for r in range(1, 4):
+            for c in (0, 1):
+                cur[r - 1][E.HALO_RECV_HI][c].copy_(cur[r][E.HALO_SEND_DOWN][c])
+        for e in engs:
+            e.fused(n, E.PART_INTERIOR)
+            e.fused_top()
+        for r in range(3):
+            for c in (0, 1):
+                cur[r + 1][E.HALO_RECV_LO][c].copy_(cur[r][E.HALO_SEND_UP][c])
+    got = [sum(e.checksum(i) for e in engs) % 2 ** 64 for i in FIELDS]
+    assert got == want
