@@ -15,6 +15,10 @@ Environment knobs for experiments (the defaults are the graded configuration):
   FDTD_BENCH_N=512       edge length per GPU instead of 1024
   FDTD_BENCH_MU=0        constant mu0 instead of a mu grid
   FDTD_BENCH_CPU=0       skip the CPU baseline leg
+  FDTD_BENCH_NZ=2048     total layers along z (default: edge length x number of GPUs)
+  FDTD_BENCH_BACKEND=gloo, FDTD_BENCH_ONE_DEVICE=1
+                         rehearsal of the multi-rank path on a box with one GPU: every rank uses cuda:0
+                         and the ghost planes travel through gloo instead of RCCL
   FDTD_BENCH_MODE=lean   two half-step kernels over D,B-only storage instead of the fused default
   FDTD_BENCH_MODE=full   two half-step kernels, E and H resident too (the reference's storage)
 """
@@ -89,9 +93,15 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         args.gpus = world
+    backend = os.environ.get("FDTD_BENCH_BACKEND", "nccl")
+    if os.environ.get("FDTD_BENCH_ONE_DEVICE", "0") == "1":
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     n_edge = int(os.environ.get("FDTD_BENCH_N", "1024"))
     has_mu = os.environ.get("FDTD_BENCH_MU", "1") != "0"
@@ -100,7 +110,7 @@ def main():
         raise SystemExit(f"FDTD_BENCH_MODE={mode_name}: expected fused, lean or full")
     lean = mode_name == "lean"
     Nx = Ny = n_edge
-    Nz = n_edge * world
+    Nz = int(os.environ.get("FDTD_BENCH_NZ", str(n_edge * world)))
     npml = (20,) * 6
     K = fs.constants()
     d = (1053e-9 / 20,) * 3                      # the reference's cell: lambda0 / 20
@@ -169,6 +179,12 @@ def main():
     sums = [eng.sumsq(i) for i in (fdtd_amd.engine.DX, fdtd_amd.engine.BY)]
     finite = all(v == v and v < float("inf") for v in sums)
     ex_energy = sums[0]
+    # order-independent checksum of Dx over the whole grid: equal for every decomposition of the same problem
+    csum = eng.checksum(fdtd_amd.engine.DX)
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, csum)
+        csum = sum(parts) % 2 ** 64
 
     # HBM-side bytes per launch from the PMC passes recorded under profiles/ (the counters cannot be
     # read from inside this process); only reported when this run is the configuration they were taken on
@@ -204,7 +220,7 @@ def main():
                          "ms_per_step_e_half": t_e * 1e3, "ms_per_step_h_half": t_h * 1e3, "ms_per_step_fused": t_f * 1e3,
                          "launches_per_step": {"k3_half_e": n_e / steps_, "k3_half_h": n_h / steps_, "k3_fused": n_f / steps_},
                          "whole_step_frac": (cells_local * world * bytes_step * args.steps / el / 1e9) / (HBM_PEAK_GBS * world)},
-            "checks": {"finite": bool(finite), "sumsq_dx_rank0": ex_energy},
+            "checks": {"finite": bool(finite), "sumsq_dx_rank0": ex_energy, "checksum_dx": csum},
         }
         if world == 1 and os.environ.get("FDTD_BENCH_CPU", "1") != "0":
             out["cpu_baseline"] = cpu_baseline()

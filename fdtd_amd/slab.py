@@ -42,34 +42,58 @@ class HaloExchange:
         self.rank, self.world, self.group = rank, world, group
         self.send_up, self.recv_lo, self.send_down, self.recv_hi = list(send_up), list(recv_lo), list(send_down), list(recv_hi)
 
-    def _post(self, ops):
+    def _staged(self) -> bool:
+        """Device planes over a backend without device point-to-point (gloo): stage through the host.
+        Only for rehearsing the multi-rank path on a box without RCCL peers."""
         import torch.distributed as dist
-        return dist.batch_isend_irecv(ops) if ops else []
+        t = (self.send_up + self.recv_lo + self.send_down + self.recv_hi)[0]
+        return bool(getattr(t, "is_cuda", False)) and dist.get_backend(self.group) == "gloo"
+
+    def _post(self, sends, send_to, recvs, recv_from):
+        import torch.distributed as dist
+        if not self._staged():
+            ops = [dist.P2POp(dist.isend, t, send_to, self.group) for t in sends]
+            ops += [dist.P2POp(dist.irecv, t, recv_from, self.group) for t in recvs]
+            return dist.batch_isend_irecv(ops) if ops else []
+        reqs = [_StagedSend(dist.isend(t.cpu(), send_to, self.group)) for t in sends]
+        reqs += [_StagedRecv(t, recv_from, self.group) for t in recvs]
+        return reqs
 
     def start_up(self):
         """Top owned H planes -> rank+1's low ghost; own low ghost <- rank-1."""
-        import torch.distributed as dist
-        ops = []
-        if self.rank + 1 < self.world:
-            ops += [dist.P2POp(dist.isend, t, self.rank + 1, self.group) for t in self.send_up]
-        if self.rank > 0:
-            ops += [dist.P2POp(dist.irecv, t, self.rank - 1, self.group) for t in self.recv_lo]
-        return self._post(ops)
+        up, down = self.rank + 1 < self.world, self.rank > 0
+        return self._post(self.send_up if up else [], self.rank + 1, self.recv_lo if down else [], self.rank - 1)
 
     def start_down(self):
         """Lowest owned E planes -> rank-1's high ghost; own high ghost <- rank+1."""
-        import torch.distributed as dist
-        ops = []
-        if self.rank > 0:
-            ops += [dist.P2POp(dist.isend, t, self.rank - 1, self.group) for t in self.send_down]
-        if self.rank + 1 < self.world:
-            ops += [dist.P2POp(dist.irecv, t, self.rank + 1, self.group) for t in self.recv_hi]
-        return self._post(ops)
+        up, down = self.rank + 1 < self.world, self.rank > 0
+        return self._post(self.send_down if down else [], self.rank - 1, self.recv_hi if up else [], self.rank + 1)
 
     @staticmethod
     def wait(reqs) -> None:
         for r in reqs:
             r.wait()
+
+
+class _StagedSend:
+    def __init__(self, req):
+        self.req = req
+
+    def wait(self):
+        self.req.wait()
+
+
+class _StagedRecv:
+    def __init__(self, target, src, group):
+        import torch
+        import torch.distributed as dist
+        self.target = target
+        self.buf = torch.empty(target.shape, dtype=target.dtype, device="cpu")
+        self.req = dist.irecv(self.buf, src, group)
+
+    def wait(self):
+        self.req.wait()
+        self.target.copy_(self.buf)
 
 
 class FusedSlabStepper:

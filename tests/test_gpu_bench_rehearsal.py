@@ -1,0 +1,44 @@
+"""bench.py's multi-rank path rehearsed on one GPU: two ranks share cuda:0, the ghost planes travel
+through gloo (host-staged) where the 8-GPU run uses RCCL.  Everything else is the code the scaling
+run executes: slab engines in separate processes, the steppers' launch/exchange order, the rank-0
+JSON line.  The global Dx checksum must equal the single-process run of the same grid."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(env_extra, ranks):
+    env = dict(os.environ, FDTD_BENCH_N="192", FDTD_BENCH_NZ="384", FDTD_BENCH_CPU="0", **env_extra)
+    if ranks == 1:
+        cmd = [sys.executable, "bench.py", "--steps", "7", "--warmup", "2"]
+    else:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env.update(FDTD_BENCH_BACKEND="gloo", FDTD_BENCH_ONE_DEVICE="1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), "bench.py", "--gpus", str(ranks), "--steps", "7", "--warmup", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("mode", ["fused", "lean"])
+def test_two_and_three_ranks_equal_one(mode):
+    one = _bench({"FDTD_BENCH_MODE": mode}, 1)
+    assert one["checks"]["finite"] and one["checks"]["checksum_dx"] != 0
+    for ranks in (2, 3):
+        many = _bench({"FDTD_BENCH_MODE": mode}, ranks)
+        assert many["n_gpus"] == ranks and many["config"]["grid"] == one["config"]["grid"]
+        assert many["checks"]["checksum_dx"] == one["checks"]["checksum_dx"]
+        for key in ("metric", "value", "unit", "ms_per_step", "roofline", "scaling", "dtype", "config"):
+            assert key in many
