@@ -211,7 +211,7 @@ def main():
                        "storage": {"fused": "D,B resident in two buffer sets; E=D/eps, H=B/mu formed in registers; one kernel per step",
                                    "lean": "D,B resident; E=D/eps, H=B/mu recomputed in the consuming kernel; two kernels per step",
                                    "full": "D,E,B,H resident; two kernels per step"}[mode_name],
-                       "device_bytes_per_gpu": eng.device_bytes()},
+                       "device_bytes_per_gpu": eng.device_bytes(), "placement_probe_ms": [round(v, 3) for v in eng.placement_probes()]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": cells_local * dom_bytes,

@@ -122,6 +122,7 @@ struct fdtd3d_engine {
     virtual int fused_part(int n, int part, hipStream_t s) = 0;
     virtual int parity() = 0;
     virtual int fused_top(hipStream_t s) = 0;
+    virtual int placement(double* ms, int cap) = 0;
     virtual int halo(int which, int comp, void** p, size_t* bytes, int at_parity) = 0;
     virtual int reduce(int id, double* sumsq, uint64_t* checksum, hipStream_t s) = 0;
     virtual size_t device_bytes() = 0;
@@ -195,6 +196,29 @@ struct Engine3 : fdtd3d_engine {
         return FDTD_OK;
     }
 
+    std::vector<double> placement_log;   // ms per probe step of every placement tried
+    int placement(double* ms, int cap) override {
+        for (int q = 0; q < cap && q < (int)placement_log.size(); ++q) ms[q] = placement_log[q];
+        return (int)placement_log.size();
+    }
+    // Four steps with the source off on the all-zero state: timing only, the state stays zero.
+    int probe(double* ms_per_step) {
+        hipEvent_t e0, e1;
+        FDTD_HIP(hipEventCreate(&e0)); FDTD_HIP(hipEventCreate(&e1));
+        const int n_off = (int)wf.size();          // past the waveform: no source term
+        int rc = step(n_off, 0);                   // warm-up: code objects, first touch
+        if (!rc) rc = step(n_off, 0);
+        FDTD_HIP(hipEventRecord(e0, 0));
+        for (int q = 0; q < 4 && !rc; ++q) rc = step(n_off, 0);
+        FDTD_HIP(hipEventRecord(e1, 0));
+        FDTD_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        FDTD_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        *ms_per_step = ms / 4;
+        return rc;
+    }
+
     int allocate_all() {
         int rc;
         for (int f = 0; f < 6; ++f) for (int c = 0; c < 3; ++c) {
@@ -254,10 +278,34 @@ struct Engine3 : fdtd3d_engine {
         planning = true; arena_used = 0; n_carved = 0;
         if ((rc = allocate_all())) return rc;
         planning = false;
-        arena_cap = arena_used; arena_used = 0; n_carved = 0;
-        FDTD_HIP(hipMalloc((void**)&arena, arena_cap));
-        allocs.push_back(arena);
-        if ((rc = allocate_all())) return rc;
+        arena_cap = arena_used;
+        // Where the driver places a large allocation in physical memory changes the streaming rate of
+        // the step kernels by up to 10 % (measured: the same binary and virtual address run a 1024^3 step
+        // in 18.1, 18.9 or 20.0 ms, cycling with every free + allocate, across processes).  For large
+        // grids the arena is therefore placed a few times, each placement timed with four source-free
+        // steps on the zero state (which they leave unchanged), until one is as fast as the best seen.
+        int tries = arena_cap >= ((size_t)8 << 30) ? 6 : 1;
+        if (const char* e = getenv("FDTD_PLACEMENT_TRIES")) { int v = atoi(e); if (v >= 1 && v <= 16) tries = v; }
+        int explore = 3;                 // placements timed before the first may be accepted
+        if (const char* e = getenv("FDTD_PLACEMENT_EXPLORE")) { int v = atoi(e); if (v >= 1 && v <= 16) explore = v; }
+        double best = 1e300;
+        for (int t = 0;; ++t) {
+            arena_used = 0; n_carved = 0; bytes = 0;
+            FDTD_HIP(hipMalloc((void**)&arena, arena_cap));
+            allocs.push_back(arena);
+            if ((rc = allocate_all())) return rc;
+            if (tries <= 1) break;
+            double ms = 0;
+            if ((rc = probe(&ms))) return rc;
+            const bool explored = t + 1 >= explore || t + 1 >= tries;
+            best = std::min(best, ms);
+            placement_log.push_back(ms);
+            if ((explored && ms <= best * 1.01) || t + 1 >= tries) break;
+            FDTD_HIP(hipFree(arena));
+            allocs.clear(); arena = nullptr;
+        }
+        flips = 0;
+        if (getenv("FDTD_PLACEMENT_DEBUG")) { fprintf(stderr, "[fdtd] placement probes (ms/step):"); for (double v : placement_log) fprintf(stderr, " %.3f", v); fprintf(stderr, "\n"); }
         tab_h.assign((size_t)3 * 2 * 6 * kMaxLayers, 0.0);
         wf.assign(d.n_wf > 0 ? d.n_wf : 0, (T)0);
         return upload_tables();
@@ -754,6 +802,7 @@ int fdtd3d_step(fdtd3d_handle h, int n0, int count, void* stream) {
 }
 int fdtd3d_fused(fdtd3d_handle h, int n, int part, void* stream) { return h ? h->fused_part(n, part, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
 int fdtd3d_fused_top(fdtd3d_handle h, void* stream) { return h ? h->fused_top((hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_placement_probes(fdtd3d_handle h, double* ms, int cap) { return (h && (ms || cap == 0)) ? h->placement(ms, cap) : 0; }
 int fdtd3d_buffer_parity(fdtd3d_handle h) { return h ? h->parity() : 0; }
 int fdtd3d_half_e(fdtd3d_handle h, int n, int part, void* stream) { return h ? h->half_e(n, part, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
 int fdtd3d_half_h(fdtd3d_handle h, int part, void* stream) { return h ? h->half_h(part, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }

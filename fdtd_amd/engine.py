@@ -15,7 +15,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfdtd_engine.so")
+# FDTD_ENGINE_LIB: another build of the same library (kernel experiments); the product path is the in-tree file
+LIB_PATH = os.environ.get("FDTD_ENGINE_LIB") or os.path.join(_HERE, "libfdtd_engine.so")
 
 # array ids (include/fdtd_engine.h)
 DX, DY, DZ, EX, EY, EZ, BX, BY, BZ, HX, HY, HZ = range(12)
@@ -164,6 +165,12 @@ class Engine3D(_Common):
     def fused_top(self, stream=None) -> None:
         """Finish B of the top owned layer after the upper neighbour's D has arrived (no-op on the last slab)."""
         _check(lib().fdtd3d_fused_top(self.h, _stream_handle(stream)), "fdtd3d_fused_top")
+
+    def placement_probes(self):
+        """Step times (ms) of the device-memory placements tried at creation (empty for small engines)."""
+        buf = (C.c_double * 16)()
+        n = lib().fdtd3d_placement_probes(self.h, buf, C.c_int(16))
+        return [buf[i] for i in range(min(n, 16))]
 
     def parity(self) -> int:
         """Which of the two D/B buffer sets is current (changes with every fused step)."""

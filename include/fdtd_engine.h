@@ -171,6 +171,13 @@ int fdtd3d_observe_accumulate(fdtd3d_handle h, double weight, int reset, void* s
 int fdtd3d_observe_rms(fdtd3d_handle h, double* host, size_t n);
 int fdtd3d_observe_frame(fdtd3d_handle h, double* ex_center, double* e_mag, size_t n, void* stream);
 
+/* Large engines (>= 8 GiB of device state) are placed in device memory up to FDTD_PLACEMENT_TRIES
+ * times (environment, default 6, 1 = off) at creation: where the driver puts a large allocation
+ * changes the streaming rate of the step kernels by several percent, so each placement is timed with
+ * a few source-free steps on the zero state and the first one as fast as the best seen is kept.
+ * Returns how many placements were timed and copies up to `cap` of their step times (ms). */
+int fdtd3d_placement_probes(fdtd3d_handle h, double* ms_per_step, int cap);
+
 /* Bytes of device memory held by the handle. */
 size_t fdtd3d_device_bytes(fdtd3d_handle h);
 
