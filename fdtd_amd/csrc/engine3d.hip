@@ -267,7 +267,7 @@ struct Engine3 : fdtd3d_engine {
         xwn = np[0][0] > 0 ? round_up(np[0][0] + 1, 4) : 0;
         xp0 = (d.Nx - np[0][1]) / 4 * 4;
         xwp = np[0][1] > 0 ? round_up(d.Nx - xp0, 4) : 0;
-        if (fused) chunk = 16;           // the closing plane of a chunk is computed twice: longer chunks pay off
+        if (fused) chunk = 24;           // the closing plane of a chunk is computed twice: longer chunks pay off
         if (const char* e = getenv("FDTD_Z_CHUNK")) { int c = atoi(e); if (c >= 1 && c <= 4096) chunk = c; }
         if (const char* e = getenv("FDTD_XCD_REMAP")) remap = atoi(e) != 0;
         if (const char* e = getenv("FDTD_FUSED_VEC")) { int v = atoi(e); if (v == V || v == V / 2) fvec = v; }
@@ -681,7 +681,8 @@ struct Engine3 : fdtd3d_engine {
     }
     int fused_part(int n, int part, hipStream_t s) override {
         if (!fused) return fail(FDTD_ERR_STATE, "fused stepping needs an engine created with FDTD3D_MODE_FUSED");
-        const int lo = 1, hi = last_rank ? nzp : nzp - 1, cut = std::min(lo + chunk, hi);
+        // EDGE only has to produce layer z_lo early; a short chunk keeps that poorly filled launch small
+        const int lo = 1, hi = last_rank ? nzp : nzp - 1, cut = std::min(lo + std::min(chunk, 8), hi);
         int kl0, kl1;
         if (part == FDTD3D_PART_ALL) { kl0 = lo; kl1 = hi; }
         else if (part == FDTD3D_PART_EDGE) { kl0 = lo; kl1 = cut; }

@@ -128,7 +128,7 @@ int fdtd3d_half_h(fdtd3d_handle h, int part, void* stream);
  * cell for cell in the same operation order), reading the current D, B and D-side CPML buffers
  * and writing the other set; the two sets change roles when the first part of a step is launched.
  *   PART_ALL       the whole slab.
- *   PART_EDGE      the lowest planes (one chunk, see fdtd3d_tune), so that D of layer z_lo can
+ *   PART_EDGE      the lowest planes (at most 8), so that D of layer z_lo can
  *                  travel down while PART_INTERIOR, which must follow, computes the rest.
  * A slab below another one leaves B of its top layer z_hi-1 unchanged: once the upper
  * neighbour's D has arrived in the high ghost plane, fdtd3d_fused_top() finishes it with the

@@ -92,7 +92,7 @@ class FusedLine(Line):
 
     def fused(self, n, part, stream=None):
         lo, hi = 1, (self.nzl + 2 if self.last else self.nzl + 1)
-        cut = min(lo + self.chunk, hi)
+        cut = min(lo + min(self.chunk, 3), hi)          # the engine also uses a shorter chunk for EDGE
         kl0, kl1 = {slab.PART_ALL: (lo, hi), slab.PART_EDGE: (lo, cut), slab.PART_INTERIOR: (cut, hi)}[part]
         assert (part == slab.PART_INTERIOR) == self.mid
         old, new = (1 - self.cur, self.cur) if self.mid else (self.cur, 1 - self.cur)
