@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -88,6 +89,82 @@ __host__ __device__ __forceinline__ double hash_unit(uint64_t seed, uint32_t str
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z = z ^ (z >> 31);
     return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ---- probe time series: a handful of cells sampled after every step without leaving the device ----
+struct ProbeSpec { int num, den; long long off; };      // value = arr[num][off], divided by arr[den][off] (den >= 0) or by `scalar` (den == -2)
+template <typename T, int N> struct PtrTable { const T* p[N]; T scalar; };
+template <typename T, int N>
+__global__ void k_probe(PtrTable<T, N> t, const ProbeSpec* __restrict__ ps, int n_probes, T* __restrict__ row) {
+    const int q = threadIdx.x;
+    if (q >= n_probes) return;
+    const ProbeSpec s = ps[q];
+    T v = t.p[s.num][s.off];
+    if (s.den >= 0) v = v / t.p[s.den][s.off];
+    else if (s.den == -2) v = v / t.scalar;
+    row[q] = v;
+}
+constexpr int kMaxProbes = 64;
+
+// Host-side bookkeeping of the sample buffer ([sample][probe], grown by doubling).
+template <typename T>
+struct ProbeLog {
+    std::vector<ProbeSpec> specs;
+    ProbeSpec* specs_d = nullptr;
+    T* buf = nullptr;
+    int rows = 0, cap = 0;
+    bool dirty = true;
+    int add(const ProbeSpec& s);
+    int next_row(T** row, int want_cap);        // makes room, uploads specs if needed, returns the row to fill
+    int read(double* out, size_t cap_values, int* n_samples, int* n_probes);
+    void reset(bool drop_probes) { rows = 0; if (drop_probes) { specs.clear(); dirty = true; } }
+    void release();
+};
+template <typename T> int ProbeLog<T>::add(const ProbeSpec& s) {
+    if ((int)specs.size() >= kMaxProbes) return fail(FDTD_ERR_ARG, "at most %d probes", kMaxProbes);
+    if (rows > 0) return fail(FDTD_ERR_STATE, "probes must be added before the first sample is recorded (or after a reset)");
+    specs.push_back(s);
+    dirty = true;
+    return FDTD_OK;
+}
+template <typename T> int ProbeLog<T>::next_row(T** row, int want_cap) {
+    if (dirty) {
+        if (!specs_d) FDTD_HIP(hipMalloc((void**)&specs_d, kMaxProbes * sizeof(ProbeSpec)));
+        FDTD_HIP(hipMemcpy(specs_d, specs.data(), specs.size() * sizeof(ProbeSpec), hipMemcpyHostToDevice));
+        dirty = false;
+    }
+    if (rows >= cap) {
+        const int ncap = std::max(std::max(want_cap, 64), cap * 2);
+        T* nb = nullptr;
+        FDTD_HIP(hipMalloc((void**)&nb, (size_t)ncap * kMaxProbes * sizeof(T)));
+        if (buf) {
+            FDTD_HIP(hipDeviceSynchronize());
+            FDTD_HIP(hipMemcpy(nb, buf, (size_t)rows * kMaxProbes * sizeof(T), hipMemcpyDeviceToDevice));
+            (void)hipFree(buf);
+        }
+        buf = nb; cap = ncap;
+    }
+    *row = buf + (size_t)rows * kMaxProbes;
+    ++rows;
+    return FDTD_OK;
+}
+template <typename T> int ProbeLog<T>::read(double* out, size_t cap_values, int* n_samples, int* n_probes) {
+    const int np = (int)specs.size();
+    if (n_samples) *n_samples = rows;
+    if (n_probes) *n_probes = np;
+    if (!out) return FDTD_OK;
+    if (cap_values < (size_t)rows * np) return fail(FDTD_ERR_ARG, "probe_read: room for %zu values, %zu recorded", cap_values, (size_t)rows * np);
+    if (rows == 0 || np == 0) return FDTD_OK;
+    std::vector<T> st((size_t)rows * kMaxProbes);
+    FDTD_HIP(hipDeviceSynchronize());
+    FDTD_HIP(hipMemcpy(st.data(), buf, st.size() * sizeof(T), hipMemcpyDeviceToHost));
+    for (int r = 0; r < rows; ++r) for (int q = 0; q < np; ++q) out[(size_t)r * np + q] = (double)st[(size_t)r * kMaxProbes + q];
+    return FDTD_OK;
+}
+template <typename T> void ProbeLog<T>::release() {
+    if (buf) (void)hipFree(buf);
+    if (specs_d) (void)hipFree(specs_d);
+    buf = nullptr; specs_d = nullptr;
 }
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }

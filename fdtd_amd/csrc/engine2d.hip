@@ -62,6 +62,10 @@ struct fdtd2d_engine {
     virtual size_t device_bytes() = 0;
     virtual int observe_accumulate(double weight, int reset, hipStream_t s) = 0;
     virtual int observe_rms(double* host, size_t n) = 0;
+    virtual int probe_add(int id, int i, int k) = 0;
+    virtual int probe_record(hipStream_t s) = 0;
+    virtual int probe_read(double* out, size_t cap, int* n_samples, int* n_probes) = 0;
+    virtual int probe_reset(int drop_probes) = 0;
     fdtd2d_desc d;
     KernelTimer timer;
 };
@@ -85,7 +89,36 @@ struct Engine2 : fdtd2d_engine {
     int chunk = 32, remap = 1;
     std::vector<void*> allocs;
 
-    ~Engine2() override { for (void* p : allocs) (void)hipFree(p); timer.release(); }
+    ~Engine2() override { for (void* p : allocs) (void)hipFree(p); probes.release(); timer.release(); }
+
+    // ---- probe time series: the sample arrays change places every step, so a probe names a slot of
+    // this table (0-2 Dy,Bx,Bz; 3-5 current sample; 6-8 older sample; 9-11 / 12-14 the same for S; 15-17 C)
+    ProbeLog<T> probes;
+    int probe_add(int id, int i, int k) override {
+        Map m;
+        if (!((id >= 0 && id <= 20) || (id >= FDTD2D_C1 && id <= FDTD2D_C3)) || !make_map(id, m)) return fail(FDTD_ERR_ARG, "probe_add: %d is not a field array", id);
+        if (i < 0 || i >= m.n0 || k < 0 || k >= m.n1) return fail(FDTD_ERR_ARG, "probe_add: cell (%d,%d) outside array %d", i, k, id);
+        const long long off = dev_off(m, i, k);
+        if (off < 0) return fail(FDTD_ERR_ARG, "probe_add: column %d of array %d is the wall column, always zero", i, id);
+        int slot;
+        if (id >= FDTD2D_C1) slot = 15 + (id - FDTD2D_C1);
+        else { const int f = id / 7, r = id % 7; slot = r == 0 ? f : (r <= 2 ? 3 + f : (r == 3 ? 6 + f : (r <= 5 ? 9 + f : 12 + f))); }
+        return probes.add(ProbeSpec{slot, -1, off});
+    }
+    int probe_record(hipStream_t s) override {
+        if (probes.specs.empty()) return FDTD_OK;
+        T* row = nullptr;
+        if (int rc = probes.next_row(&row, (int)Jy.size() + 8)) return rc;
+        PtrTable<T, 18> t;
+        t.p[0] = Dy; t.p[1] = Bx; t.p[2] = Bz;
+        for (int f = 0; f < 3; ++f) { t.p[3 + f] = Fa[f]; t.p[6 + f] = Fb[f]; t.p[9 + f] = Sa[f]; t.p[12 + f] = Sb[f]; t.p[15 + f] = C[f]; }
+        t.scalar = (T)1;
+        hipLaunchKernelGGL((k_probe<T, 18>), dim3(1), dim3(kMaxProbes), 0, s, t, probes.specs_d, (int)probes.specs.size(), row);
+        FDTD_HIP(hipGetLastError());
+        return FDTD_OK;
+    }
+    int probe_read(double* out, size_t cap, int* n_samples, int* n_probes) override { return probes.read(out, cap, n_samples, n_probes); }
+    int probe_reset(int drop_probes) override { probes.reset(drop_probes != 0); return FDTD_OK; }
 
     int dalloc(void** p, size_t nbytes) {
         if (nbytes == 0) { *p = nullptr; return FDTD_OK; }
@@ -297,6 +330,7 @@ struct Engine2 : fdtd2d_engine {
             timer.end(s);
             FDTD_HIP(hipGetLastError());
             for (int f = 1; f < 3; ++f) { std::swap(Fa[f], Fb[f]); std::swap(Sa[f], Sb[f]); }
+            if (int rc = probe_record(s)) return rc;
         }
         return FDTD_OK;
     }
@@ -337,6 +371,10 @@ int fdtd2d_sumsq(fdtd2d_handle h, int id, double* out, void* stream) { return (h
 size_t fdtd2d_device_bytes(fdtd2d_handle h) { return h ? h->device_bytes() : 0; }
 int fdtd2d_observe_accumulate(fdtd2d_handle h, double weight, int reset, void* stream) { return h ? h->observe_accumulate(weight, reset, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
 int fdtd2d_observe_rms(fdtd2d_handle h, double* host, size_t n) { return h ? h->observe_rms(host, n) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd2d_probe_add(fdtd2d_handle h, int id, int i, int k) { return h ? h->probe_add(id, i, k) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd2d_probe_record(fdtd2d_handle h, void* stream) { return h ? h->probe_record((hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd2d_probe_read(fdtd2d_handle h, double* out, size_t cap, int* n_samples, int* n_probes) { return h ? h->probe_read(out, cap, n_samples, n_probes) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd2d_probe_reset(fdtd2d_handle h, int drop_probes) { return h ? h->probe_reset(drop_probes) : fail(FDTD_ERR_ARG, "null handle"); }
 int fdtd2d_kernel_timing(fdtd2d_handle h, int enable) { if (!h) return fail(FDTD_ERR_ARG, "null handle"); h->timer.enabled = enable != 0; return FDTD_OK; }
 int fdtd2d_kernel_time(fdtd2d_handle h, int kind, int* launches, double* total_ms) { return h ? h->timer.collect(kind, launches, total_ms) : fail(FDTD_ERR_ARG, "null handle"); }
 

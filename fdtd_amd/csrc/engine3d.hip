@@ -123,6 +123,11 @@ struct fdtd3d_engine {
     virtual int parity() = 0;
     virtual int fused_top(hipStream_t s) = 0;
     virtual int placement(double* ms, int cap) = 0;
+    virtual int probe_add(int id, int i, int j, int k) = 0;
+    virtual int probe_record(hipStream_t s) = 0;
+    virtual int probe_read(double* out, size_t cap, int* n_samples, int* n_probes) = 0;
+    virtual int probe_reset(int drop_probes) = 0;
+    virtual int probe_count() = 0;
     virtual int halo(int which, int comp, void** p, size_t* bytes, int at_parity) = 0;
     virtual int reduce(int id, double* sumsq, uint64_t* checksum, hipStream_t s) = 0;
     virtual size_t device_bytes() = 0;
@@ -165,8 +170,41 @@ struct Engine3 : fdtd3d_engine {
 
     ~Engine3() override {
         for (void* p : allocs) (void)hipFree(p);
+        probes.release();
         timer.release();
     }
+
+    // ---- probe time series ----------------------------------------------------------------
+    ProbeLog<T> probes;
+    int probe_count() override { return (int)probes.specs.size(); }
+    int probe_add(int id, int i, int j, int k) override {
+        Map m;
+        if (id < 0 || id >= 18 || !make_map(id, m)) return fail(FDTD_ERR_ARG, "probe_add: %d is not a field array", id);
+        if (i < 0 || i >= m.n[0] || j < 0 || j >= m.n[1] || k < 0 || k >= m.n[2]) return fail(FDTD_ERR_ARG, "probe_add: cell (%d,%d,%d) outside array %d", i, j, k, id);
+        bool owned;
+        const long long off = dev_off(m, i, j, k, owned);
+        if (off == -2) return fail(FDTD_ERR_ARG, "probe_add: column %d of array %d is the wall column, always zero", i, id);
+        if (off < 0 || !owned) return fail(FDTD_ERR_ARG, "probe_add: layer %d is not owned by this slab [%d,%d)", k, d.z_lo, d.z_hi);
+        ProbeSpec sp{id, -1, off};
+        const int fam = id / 3, c = id % 3;
+        if (!full && fam == 1) { sp.num = c; sp.den = 12 + c; }
+        if (!full && fam == 3) { sp.num = 6 + c; sp.den = d.has_mu ? 15 + c : -2; }
+        if (!fld[sp.num]) return fail(FDTD_ERR_ARG, "probe_add: array %d is not resident", id);
+        return probes.add(sp);
+    }
+    int probe_record(hipStream_t s) override {
+        if (probes.specs.empty()) return FDTD_OK;
+        T* row = nullptr;
+        if (int rc = probes.next_row(&row, (int)wf.size() + 8)) return rc;
+        PtrTable<T, 18> t;
+        for (int q = 0; q < 18; ++q) t.p[q] = fld[q];
+        t.scalar = (T)d.mu0;
+        hipLaunchKernelGGL((k_probe<T, 18>), dim3(1), dim3(kMaxProbes), 0, s, t, probes.specs_d, (int)probes.specs.size(), row);
+        FDTD_HIP(hipGetLastError());
+        return FDTD_OK;
+    }
+    int probe_read(double* out, size_t cap, int* n_samples, int* n_probes) override { return probes.read(out, cap, n_samples, n_probes); }
+    int probe_reset(int drop_probes) override { probes.reset(drop_probes != 0); return FDTD_OK; }
 
     // All arrays of the time loop are carved from one device allocation.  Consecutive arrays start
     // `skew` bytes further into the 4 KB granule than their predecessor, so that the dozen-odd streams
@@ -797,12 +835,18 @@ int fdtd3d_fill_materials(fdtd3d_handle h, uint64_t seed, double elo, double ehi
 int fdtd3d_step(fdtd3d_handle h, int n0, int count, void* stream) {
     if (!h) return fail(FDTD_ERR_ARG, "null handle");
     if (h->d.z_lo != 0 || h->d.z_hi != h->d.Nz) return fail(FDTD_ERR_STATE, "fdtd3d_step needs the whole grid on this device; slab drivers use fdtd3d_half_e / fdtd3d_half_h");
-    for (int n = n0; n < n0 + count; ++n)
+    for (int n = n0; n < n0 + count; ++n) {
         if (int rc = h->step(n, (hipStream_t)stream)) return rc;
+        if (int rc = h->probe_record((hipStream_t)stream)) return rc;
+    }
     return FDTD_OK;
 }
 int fdtd3d_fused(fdtd3d_handle h, int n, int part, void* stream) { return h ? h->fused_part(n, part, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
 int fdtd3d_fused_top(fdtd3d_handle h, void* stream) { return h ? h->fused_top((hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_probe_add(fdtd3d_handle h, int id, int i, int j, int k) { return h ? h->probe_add(id, i, j, k) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_probe_record(fdtd3d_handle h, void* stream) { return h ? h->probe_record((hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_probe_read(fdtd3d_handle h, double* out, size_t cap, int* n_samples, int* n_probes) { return h ? h->probe_read(out, cap, n_samples, n_probes) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_probe_reset(fdtd3d_handle h, int drop_probes) { return h ? h->probe_reset(drop_probes) : fail(FDTD_ERR_ARG, "null handle"); }
 int fdtd3d_placement_probes(fdtd3d_handle h, double* ms, int cap) { return (h && (ms || cap == 0)) ? h->placement(ms, cap) : 0; }
 int fdtd3d_buffer_parity(fdtd3d_handle h) { return h ? h->parity() : 0; }
 int fdtd3d_half_e(fdtd3d_handle h, int n, int part, void* stream) { return h ? h->half_e(n, part, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }

@@ -114,6 +114,29 @@ class _Common:
     def device_bytes(self) -> int:
         return self._fn("device_bytes")(self.h)
 
+    # ---- probe time series (samples stay on the device until read) ----
+    def probe_add(self, id_: int, *cell) -> None:
+        """Sample array `id_` at canonical cell (i, j, k) [3-D] or (i, k) [2-D] after every step."""
+        _check(self._fn("probe_add")(self.h, C.c_int(id_), *[C.c_int(int(c)) for c in cell]), f"probe_add({id_}, {cell})")
+        self.probe_count = getattr(self, "probe_count", 0) + 1
+
+    def probe_record(self, stream=None) -> None:
+        _check(self._fn("probe_record")(self.h, _stream_handle(stream)), "probe_record")
+
+    def probe_read(self) -> np.ndarray:
+        """[samples, probes] array of everything recorded so far."""
+        ns, npr = C.c_int(0), C.c_int(0)
+        _check(self._fn("probe_read")(self.h, None, C.c_size_t(0), C.byref(ns), C.byref(npr)), "probe_read")
+        out = np.zeros((ns.value, npr.value))
+        if out.size:
+            _check(self._fn("probe_read")(self.h, out.ctypes.data_as(_dp), C.c_size_t(out.size), C.byref(ns), C.byref(npr)), "probe_read")
+        return out
+
+    def probe_reset(self, drop_probes: bool = False) -> None:
+        _check(self._fn("probe_reset")(self.h, C.c_int(int(drop_probes))), "probe_reset")
+        if drop_probes:
+            self.probe_count = 0
+
     def kernel_timing(self, enable: bool) -> None:
         _check(self._fn("kernel_timing")(self.h, C.c_int(int(enable))), "kernel_timing")
 

@@ -121,6 +121,8 @@ class FusedSlabStepper:
         HaloExchange.wait(pending_d)                 # new D of layer z_hi
         e.fused_top(s)
         self._pending_b = x.start_up()
+        if getattr(e, "probe_count", 0):
+            e.probe_record(s)
 
     def run(self, n0: int, count: int) -> None:
         for n in range(n0, n0 + count):
@@ -150,6 +152,8 @@ class SlabStepper:
         HaloExchange.wait(pending_e)
         e.half_h(PART_EDGE, s)
         self._pending_h = self.x.start_up()
+        if getattr(e, "probe_count", 0):
+            e.probe_record(s)
 
     def run(self, n0: int, count: int) -> None:
         for n in range(n0, n0 + count):

@@ -171,6 +171,19 @@ int fdtd3d_observe_accumulate(fdtd3d_handle h, double weight, int reset, void* s
 int fdtd3d_observe_rms(fdtd3d_handle h, double* host, size_t n);
 int fdtd3d_observe_frame(fdtd3d_handle h, double* ex_center, double* e_mag, size_t n, void* stream);
 
+/* Probe time series (no counterpart in the reference, which has no probes; the value sampled is the
+ * one a read of the reference's vector at that cell would give after the step).  Up to 64 cells of
+ * field arrays (ids 0..17), given by canonical (i, j, k); a slab engine only accepts cells of layers
+ * it owns.  fdtd3d_step records one sample of every probe after each step; slab drivers call
+ * fdtd3d_probe_record() themselves at the end of a step.  Samples are kept on the device;
+ * fdtd3d_probe_read() synchronises and returns them sample-major, out[sample * n_probes + probe]
+ * (out may be NULL to query the counts).  Probes are added before the first sample or after
+ * fdtd3d_probe_reset(h, 1); reset(h, 0) only drops the samples. */
+int fdtd3d_probe_add(fdtd3d_handle h, int id, int i, int j, int k);
+int fdtd3d_probe_record(fdtd3d_handle h, void* stream);
+int fdtd3d_probe_read(fdtd3d_handle h, double* out, size_t cap, int* n_samples, int* n_probes);
+int fdtd3d_probe_reset(fdtd3d_handle h, int drop_probes);
+
 /* Large engines (>= 8 GiB of device state) are placed in device memory up to FDTD_PLACEMENT_TRIES
  * times (environment, default 6, 1 = off) at creation: where the driver puts a large allocation
  * changes the streaming rate of the step kernels by several percent, so each placement is timed with
@@ -243,6 +256,12 @@ int fdtd2d_sumsq(fdtd2d_handle h, int id, double* out, void* stream);
 int fdtd2d_observe_accumulate(fdtd2d_handle h, double weight, int reset, void* stream);
 int fdtd2d_observe_rms(fdtd2d_handle h, double* host, size_t n);
 size_t fdtd2d_device_bytes(fdtd2d_handle h);
+/* Probe time series, as in 3-D: cells (i, k) of the field arrays (ids 0..20) or C1..C3; fdtd2d_step
+ * records one sample per step. */
+int fdtd2d_probe_add(fdtd2d_handle h, int id, int i, int k);
+int fdtd2d_probe_record(fdtd2d_handle h, void* stream);
+int fdtd2d_probe_read(fdtd2d_handle h, double* out, size_t cap, int* n_samples, int* n_probes);
+int fdtd2d_probe_reset(fdtd2d_handle h, int drop_probes);
 int fdtd2d_kernel_timing(fdtd2d_handle h, int enable);
 int fdtd2d_kernel_time(fdtd2d_handle h, int kind, int* launches, double* total_ms);
 

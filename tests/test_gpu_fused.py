@@ -157,3 +157,42 @@ def test_fused_part_order_is_checked():
     lean = fdtd_amd.Engine3D((16, 16, 16), (0,) * 6, (1e-7,) * 3, 1e-16, K["mu0"], 4, 3, precision=32, mode=fdtd_amd.engine.MODE_LEAN)
     with pytest.raises(fdtd_amd.engine.EngineError):
         lean.fused(0)
+
+
+def test_probe_on_fused_slabs_matches_reference_series():
+    """A probe lives on the slab that owns its layer; with the slab step order (lowest chunk, rest,
+    top layer) its series must still be the reference's."""
+    from fdtd_amd import engine as E
+    from fdtd_amd import slab
+    meta, ins, outs, extra = util.load_fixture("g2_3d_cavity")
+    parts = slab.partition(meta["N"][2], 3)
+    engs = [fdtd_amd.Engine3D(meta["N"], meta["npml"], (meta["dx"], meta["dy"], meta["dz"]), meta["dt"], meta["mu0"],
+                              meta["k_Jx"], meta["steps"], precision=64, mode=MODE_FUSED, z_range=p) for p in parts]
+    cell = tuple(meta["probe_cell"])
+    owners = []
+    for e, (lo, hi) in zip(engs, parts):
+        e.tune(4, 1, 6)
+        util.feed(e, ins)
+        if lo <= cell[2] < hi:
+            e.probe_add(po.EX, *cell)
+            owners.append(e)
+        else:
+            with pytest.raises(E.EngineError):
+                e.probe_add(po.EX, *cell)
+    assert len(owners) == 1
+    pl = [[{w: [E.halo_tensor(e, w, c, par) for c in (0, 1)] for w in range(4)} for par in (0, 1)] for e in engs]
+    for n in range(meta["steps"]):
+        for e in engs:
+            e.fused(n, E.PART_EDGE)
+        cur = [pl[r][engs[r].parity()] for r in range(3)]
+        for r in range(1, 3):
+            for c in (0, 1):
+                cur[r - 1][E.HALO_RECV_HI][c].copy_(cur[r][E.HALO_SEND_DOWN][c])
+        for e in engs:
+            e.fused(n, E.PART_INTERIOR)
+            e.fused_top()
+            e.probe_record()
+        for r in range(2):
+            for c in (0, 1):
+                cur[r + 1][E.HALO_RECV_LO][c].copy_(cur[r][E.HALO_SEND_UP][c])
+    util.assert_equal_arrays(owners[0].probe_read()[:, 0], extra["probe"], "probe series on fused slabs")

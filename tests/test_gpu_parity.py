@@ -233,3 +233,43 @@ def test_ragged_shapes_2d(Nx, Nz, npml):
     for id_ in po.FIELDS2D + po.ALL_PHI2D:
         if eng.size(id_):
             util.assert_equal_arrays(eng.get(id_), tw.get(id_), f"2-D {Nx}x{Nz} array {id_}")
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_device_probe_series_3d(mode):
+    """Probe time series recorded on the device == the reference's series at the same cell (fp64), plus
+    a B-family and a D-family probe against a per-step download; every storage mode."""
+    meta, ins, outs, extra = util.load_fixture("g2_3d_cavity")
+    eng = engine3d_from_meta(meta, 64, mode=mode)
+    util.feed(eng, ins)
+    cell = tuple(meta["probe_cell"])
+    eng.probe_add(po.EX, *cell)
+    eng.probe_add(po.HY, 3, 4, 5)
+    eng.probe_add(po.DZ, 5, 6, 7)
+    with pytest.raises(fdtd_amd.engine.EngineError):
+        eng.probe_add(po.EY, meta["N"][0], 0, 0)          # wall column
+    with pytest.raises(fdtd_amd.engine.EngineError):
+        eng.probe_add(po.EX, 0, 0, meta["N"][2] + 5)       # outside
+    eng.step(0, 50)
+    hy50 = eng.get(po.HY, po.shape3d(po.HY, meta["N"], meta["npml"]))[3, 4, 5]
+    eng.step(50, meta["steps"] - 50)
+    series = eng.probe_read()
+    assert series.shape == (meta["steps"], 3)
+    util.assert_equal_arrays(series[:, 0], extra["probe"], "device probe series")
+    assert series[49, 1] == hy50
+    assert series[-1, 2] == eng.get(po.DZ, po.shape3d(po.DZ, meta["N"], meta["npml"]))[5, 6, 7]
+    with pytest.raises(fdtd_amd.engine.EngineError):
+        eng.probe_add(po.EX, 1, 1, 1)                      # samples exist: needs a reset first
+    eng.probe_reset(False)
+    assert eng.probe_read().shape == (0, 3)
+
+
+def test_device_probe_series_2d():
+    meta, ins, outs, extra = util.load_fixture("g5_2d_pec512")
+    eng = engine2d_from_meta(meta, 64)
+    util.feed(eng, ins)
+    eng.probe_add(po.D2_EY, *meta["probe_cell"])
+    eng.step(0, meta["steps"])
+    series = eng.probe_read()
+    assert series.shape == (meta["steps"], 1)
+    util.assert_equal_arrays(series[:, 0], extra["probe"], "2-D device probe series")
