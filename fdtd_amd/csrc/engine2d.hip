@@ -86,7 +86,7 @@ struct Engine2 : fdtd2d_engine {
     unsigned char* disp_d = nullptr;
     std::vector<double> tab_h;
     std::vector<T> Jy;
-    int chunk = 32, remap = 1;
+    int chunk = 1, remap = 1;      // rows per wave: at 8192^2 one row per wave is fastest (the row below comes from L2, and more waves are in flight)
     std::vector<void*> allocs;
 
     ~Engine2() override { for (void* p : allocs) (void)hipFree(p); probes.release(); timer.release(); }

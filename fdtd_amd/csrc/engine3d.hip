@@ -206,23 +206,19 @@ struct Engine3 : fdtd3d_engine {
     int probe_read(double* out, size_t cap, int* n_samples, int* n_probes) override { return probes.read(out, cap, n_samples, n_probes); }
     int probe_reset(int drop_probes) override { probes.reset(drop_probes != 0); return FDTD_OK; }
 
-    // All arrays of the time loop are carved from one device allocation.  Consecutive arrays start
-    // `skew` bytes further into the 4 KB granule than their predecessor, so that the dozen-odd streams
-    // a kernel reads at the same (row, plane) position do not all sit at the same phase of the memory
-    // channel interleave.  `planning` sums the sizes first.
+    // All arrays of the time loop are carved from one device allocation (4 KB granules), so that the
+    // whole state can be placed -- and re-placed -- in device memory as one piece.  `planning` sums the
+    // sizes first.
     char* arena = nullptr;
-    size_t arena_cap = 0, arena_used = 0, skew = 0;
-    int n_carved = 0;
+    size_t arena_cap = 0, arena_used = 0;
     bool planning = false;
     static constexpr size_t kGranule = 4096;
     int dalloc(void** p, size_t nbytes, int fill_byte_pattern_zero = 1) {
         if (nbytes == 0) { *p = nullptr; return FDTD_OK; }
-        const size_t lead = ((size_t)n_carved * skew) % kGranule;
-        const size_t span = (lead + nbytes + kGranule - 1) / kGranule * kGranule;
-        ++n_carved;
+        const size_t span = (nbytes + kGranule - 1) / kGranule * kGranule;
         if (planning) { arena_used += span; *p = nullptr; return FDTD_OK; }
         if (arena && arena_used + span <= arena_cap) {
-            *p = arena + arena_used + lead;
+            *p = arena + arena_used;
             arena_used += span;
             bytes += nbytes;
         } else {                            // arrays created after set-up (observables) stand alone
@@ -311,9 +307,8 @@ struct Engine3 : fdtd3d_engine {
         if (const char* e = getenv("FDTD_FUSED_VEC")) { int v = atoi(e); if (v == V || v == V / 2) fvec = v; }
         if (const char* e = getenv("FDTD_ROWS_PER_GROUP")) { int w = atoi(e); if (w >= 1 && w <= 4) wpb = w; }
 
-        if (const char* e = getenv("FDTD_ARRAY_SKEW")) { long v = atol(e); if (v >= 0 && v % 256 == 0) skew = (size_t)v; }
         int rc;
-        planning = true; arena_used = 0; n_carved = 0;
+        planning = true; arena_used = 0;
         if ((rc = allocate_all())) return rc;
         planning = false;
         arena_cap = arena_used;
@@ -328,7 +323,7 @@ struct Engine3 : fdtd3d_engine {
         if (const char* e = getenv("FDTD_PLACEMENT_EXPLORE")) { int v = atoi(e); if (v >= 1 && v <= 16) explore = v; }
         double best = 1e300;
         for (int t = 0;; ++t) {
-            arena_used = 0; n_carved = 0; bytes = 0;
+            arena_used = 0; bytes = 0;
             FDTD_HIP(hipMalloc((void**)&arena, arena_cap));
             allocs.push_back(arena);
             if ((rc = allocate_all())) return rc;
