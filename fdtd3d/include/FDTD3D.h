@@ -23,10 +23,11 @@ struct Sim3DConfig {
     int n_T0;              // steps per optical period: RMS window = n_T0/2, weights 4/n_T0
     int frame_every;
     bool write_files;
+    bool binary_vti;       // opt-in: raw appended Float32 VTI instead of the reference's ASCII Float64
     std::string out_dir;
     // The reference's hard-coded problem (FDTD3D.cpp:21-39, :71, FDTD3D.h:54-56).
     static Sim3DConfig reference_default();
-    // Overrides from FDTD3D_NX / _NY / _NZ / _STEPS / _NPML / _KJX / _PRECISION / _LEAN / _FUSED / _FRAME_EVERY /
+    // Overrides from FDTD3D_NX / _NY / _NZ / _STEPS / _NPML / _KJX / _PRECISION / _LEAN / _FUSED / _FRAME_EVERY / _BINARY_VTI /
     // _WRITE / _OUT environment variables (the reference's main() takes no arguments).
     void apply_environment();
 };

@@ -8,7 +8,11 @@
 
 class FieldWriter3D {
 public:
-    explicit FieldWriter3D(const std::string& directory);
+    // ascii: the reference's format, byte for byte.  appended: same header and data array, but the
+    // values follow as raw little-endian Float32 in an <AppendedData encoding="raw"> block (UInt64
+    // length prefix) -- 4 bytes per cell instead of ~20, for grids where ASCII is not an option.
+    enum class Encoding { ascii, appended };
+    explicit FieldWriter3D(const std::string& directory, Encoding encoding = Encoding::ascii);
     // values are [Nz][Ny][Nx], x fastest; file <dir>/<name>_t<step, 5 digits>.vti
     bool write_vti(const std::string& name, const std::vector<double>& values, int Nx, int Ny, int Nz,
                    double dx, double dy, double dz, int step) const;
@@ -16,4 +20,5 @@ public:
 
 private:
     std::string m_dir;
+    Encoding m_encoding;
 };

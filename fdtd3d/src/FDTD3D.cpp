@@ -43,6 +43,7 @@ Sim3DConfig Sim3DConfig::reference_default() {
     c.precision = 64;
     c.lean = true;
     c.fused = true;
+    c.binary_vti = false;
     c.n_T0 = static_cast<int>(std::round(2 * cells_per_wavelength));
     c.frame_every = 20;
     c.write_files = true;
@@ -59,6 +60,7 @@ void Sim3DConfig::apply_environment() {
     if (env_int("FDTD3D_LEAN", v)) lean = v != 0;
     if (env_int("FDTD3D_FUSED", v)) fused = v != 0;
     if (env_int("FDTD3D_WRITE", v)) write_files = v != 0;
+    if (env_int("FDTD3D_BINARY_VTI", v)) binary_vti = v != 0;
     if (const char* e = std::getenv("FDTD3D_OUT")) if (*e) out_dir = e;
 }
 
@@ -94,14 +96,8 @@ void FDTD3D::build() {
         must(fdtd3d_set_array(m_engine, FDTD3D_JX_WF, wf.data(), wf.size()), "upload waveform");
         must(fdtd3d_set_array(m_engine, FDTD3D_JX_MAG, mag.data(), mag.size()), "upload source magnitude");
     }
-    {
-        std::vector<double> ex(fdtd3d_array_size(m_engine, FDTD3D_EPS_X)), ey(fdtd3d_array_size(m_engine, FDTD3D_EPS_Y)),
-            ez(fdtd3d_array_size(m_engine, FDTD3D_EPS_Z));
-        must(fdtd3d_default_materials(c.Nx, c.Ny, c.Nz, c.dx, c.dy, c.dz, ex.data(), ey.data(), ez.data()), "default materials");
-        must(fdtd3d_set_array(m_engine, FDTD3D_EPS_X, ex.data(), ex.size()), "upload eps_x");
-        must(fdtd3d_set_array(m_engine, FDTD3D_EPS_Y, ey.data(), ey.size()), "upload eps_y");
-        must(fdtd3d_set_array(m_engine, FDTD3D_EPS_Z, ez.data(), ez.size()), "upload eps_z");
-    }
+    // setupMaterials (reference FDTD3D.cpp:106-200) runs on the device: same fp64 arithmetic, no O(N^3) host loop
+    must(fdtd3d_fill_reference_materials(m_engine), "reference materials");
     const double h[3] = {c.dx, c.dy, c.dz};
     for (int axis = 0; axis < 3; ++axis) for (int side = 0; side < 2; ++side) {
         const int n = c.n_pml[axis * 2 + side];
@@ -111,7 +107,7 @@ void FDTD3D::build() {
         for (int kind = 0; kind < 6; ++kind)
             must(fdtd3d_set_array(m_engine, FDTD3D_TAB + (axis * 2 + side) * 6 + kind, t.data() + static_cast<size_t>(kind) * n, n), "upload CPML table");
     }
-    if (c.write_files) m_out = std::make_unique<FieldWriter3D>(c.out_dir);
+    if (c.write_files) m_out = std::make_unique<FieldWriter3D>(c.out_dir, c.binary_vti ? FieldWriter3D::Encoding::appended : FieldWriter3D::Encoding::ascii);
     const size_t cells = static_cast<size_t>(c.Nx) * c.Ny * c.Nz;
     m_a.assign(cells, 0.0);
     m_b.assign(cells, 0.0);

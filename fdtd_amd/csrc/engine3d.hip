@@ -1,5 +1,6 @@
 // engine3d.hip -- host side of the 3-D engine: device state, array exchange, launches, C ABI.
 #include "kernels3d_fused.hpp"
+#include "../../include/fdtd_setup.h"
 
 #include <algorithm>
 #include <cmath>
@@ -38,6 +39,38 @@ __global__ void k_fill_hash(T* arr, CompGeom g, uint64_t seed, uint32_t stream, 
         if (i >= g.Nx || i >= g.n[0] || j >= g.n[1] || k < 0 || k >= g.n[2]) continue;
         const uint64_t canon = ((uint64_t)i * g.n[1] + j) * g.n[2] + k;
         arr[(size_t)kl * per_plane + r] = (T)(lo + (hi - lo) * hash_unit(seed, stream, canon));
+    }
+}
+
+// FDTD3D::setupMaterials (FDTD3D.cpp:106-200) evaluated per stored element in fp64, operation for
+// operation as the host generator fdtd3d_default_materials does it: component c sits half a cell along
+// its own axis, the other two axes are sampled at the node and half a cell either side (3 x 3 points);
+// the fraction of points inside the sphere blends eps_air into eps_glass.
+template <typename T>
+__global__ void k_fill_sphere(T* arr, CompGeom g, int c, int N0, int N1, int N2, double h0, double h1, double h2,
+                              double eps_glass, double eps_air, double radius, int kl_all_lo, int kl_all_hi) {
+    const size_t per_plane = (size_t)g.ny1 * g.px;
+    const size_t total = per_plane * (size_t)(kl_all_hi - kl_all_lo);
+    const int N[3] = {N0, N1, N2};
+    const double h[3] = {h0, h1, h2};
+    const int u = (c + 1) % 3 < (c + 2) % 3 ? (c + 1) % 3 : (c + 2) % 3;
+    const int v = 3 - c - u;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int kl = kl_all_lo + (int)(t / per_plane);
+        const size_t r = t % per_plane;
+        const int p[3] = {(int)(r % g.px), (int)(r / g.px), kl + g.zoff};
+        if (p[0] >= g.Nx || p[0] >= g.n[0] || p[1] >= g.n[1] || p[2] < 0 || p[2] >= g.n[2]) continue;
+        double r0[3];
+        for (int a = 0; a < 3; ++a) r0[a] = a == c ? ((p[a] + 0.5) - N[a] / 2) * h[a] : (p[a] - N[a] / 2) * h[a];
+        int hits = 0;
+        for (int su = -1; su <= 1; ++su) for (int sv = -1; sv <= 1; ++sv) {
+            double q[3] = {r0[0], r0[1], r0[2]};
+            q[u] = r0[u] + su * (h[u] * 0.5);
+            q[v] = r0[v] + sv * (h[v] * 0.5);
+            if (sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]) <= radius) ++hits;
+        }
+        const double fill = (double)hits / 9.0;
+        arr[(size_t)kl * per_plane + r] = (T)(eps_glass + (eps_air - eps_glass) * fill);
     }
 }
 
@@ -116,6 +149,7 @@ struct fdtd3d_engine {
     virtual int set_array(int id, const double* host, size_t n) = 0;
     virtual int get_array(int id, double* host, size_t n) = 0;
     virtual int fill_materials(uint64_t seed, double elo, double ehi, double mlo, double mhi) = 0;
+    virtual int fill_reference_materials() = 0;
     virtual int half_e(int n, int part, hipStream_t s) = 0;
     virtual int half_h(int part, hipStream_t s) = 0;
     virtual int step(int n, hipStream_t s) = 0;
@@ -556,6 +590,19 @@ struct Engine3 : fdtd3d_engine {
         return FDTD_OK;
     }
 
+    int fill_reference_materials() override {
+        double eps0 = 0;
+        fdtd_constants(nullptr, nullptr, &eps0, nullptr);
+        const double n_glass = 1.47, n_air = 1.0;
+        const double eps_glass = (n_glass * n_glass) * eps0, eps_air = (n_air * n_air) * eps0, radius = 2.0 * 1053e-9;
+        for (int c = 0; c < 3; ++c)
+            hipLaunchKernelGGL(k_fill_sphere<T>, dim3(4096), dim3(256), 0, 0, fld[12 + c], geom(12 + c, false), c, d.Nx, d.Ny, d.Nz,
+                               d.dx, d.dy, d.dz, eps_glass, eps_air, radius, 0, nzp);
+        FDTD_HIP(hipGetLastError());
+        FDTD_HIP(hipDeviceSynchronize());
+        return FDTD_OK;
+    }
+
     int reduce(int id, double* sumsq, uint64_t* checksum, hipStream_t s) override {
         if (id < 0 || id >= 18 || !fld[id]) return fail(FDTD_ERR_ARG, "reduce: array %d is not a resident field", id);
         FDTD_HIP(hipMemsetAsync(red_d, 0, 1025 * sizeof(double), s));
@@ -827,6 +874,7 @@ int fdtd3d_get_array(fdtd3d_handle h, int id, double* host, size_t n) { return h
 int fdtd3d_fill_materials(fdtd3d_handle h, uint64_t seed, double elo, double ehi, double mlo, double mhi) {
     return h ? h->fill_materials(seed, elo, ehi, mlo, mhi) : fail(FDTD_ERR_ARG, "null handle");
 }
+int fdtd3d_fill_reference_materials(fdtd3d_handle h) { return h ? h->fill_reference_materials() : fail(FDTD_ERR_ARG, "null handle"); }
 int fdtd3d_step(fdtd3d_handle h, int n0, int count, void* stream) {
     if (!h) return fail(FDTD_ERR_ARG, "null handle");
     if (h->d.z_lo != 0 || h->d.z_hi != h->d.Nz) return fail(FDTD_ERR_STATE, "fdtd3d_step needs the whole grid on this device; slab drivers use fdtd3d_half_e / fdtd3d_half_h");

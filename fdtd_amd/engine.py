@@ -207,6 +207,10 @@ class Engine3D(_Common):
         _check(lib().fdtd3d_fill_materials(self.h, C.c_uint64(seed), C.c_double(eps_lo), C.c_double(eps_hi),
                                            C.c_double(mu_lo), C.c_double(mu_hi)), "fdtd3d_fill_materials")
 
+    def fill_reference_materials(self) -> None:
+        """The reference's default eps (glass with an air sphere) generated on the device."""
+        _check(lib().fdtd3d_fill_reference_materials(self.h), "fdtd3d_fill_reference_materials")
+
     def halo(self, which: int, comp: int, parity=None):
         """(device pointer, bytes) of one ghost-exchange plane; `parity` selects the buffer set of a
         MODE_FUSED engine (default: the current one)."""

@@ -111,6 +111,12 @@ int fdtd3d_get_array(fdtd3d_handle h, int id, double* host, size_t n);
 int fdtd3d_fill_materials(fdtd3d_handle h, uint64_t seed, double eps_lo, double eps_hi,
                           double mu_lo, double mu_hi);
 
+/* FDTD3D::setupMaterials (FDTD3D.cpp:106-200) evaluated on the device for the layers this engine
+ * stores: fused silica (n = 1.47) with a centred air sphere of radius two wavelengths, 3 x 3
+ * sub-sampled -- fp64, operation for operation as fdtd3d_default_materials() on the host (the two
+ * agree bit for bit), without the O(N^3) single-threaded host loop and the host arrays. */
+int fdtd3d_fill_reference_materials(fdtd3d_handle h);
+
 /* Advance `count` whole steps n0, n0+1, ...: per step E-half (curl+CPML, source, E=D/eps;
  * FDTD3D::updateE) then H-half (FDTD3D::updateH).  Asynchronous on `stream`
  * (a hipStream_t, NULL = default stream).  Only valid when the slab is the whole grid. */

@@ -52,8 +52,9 @@ def test_fdtd3d_driver_full_storage_and_fp32(tmp_path):
     fx = os.path.join(util.GOLDEN, "run3d")
     meta = json.load(open(os.path.join(fx, "meta.json")))
     env = dict(FDTD3D_NX=meta["N"][0], FDTD3D_NY=meta["N"][1], FDTD3D_NZ=meta["N"][2], FDTD3D_NPML=meta["npml"][0], FDTD3D_STEPS=meta["steps"])
-    _run("fdtd3d", dict(env, FDTD3D_PRECISION=64, FDTD3D_LEAN=0), str(tmp_path))
-    _compare_dir(str(tmp_path / "output_3d"), fx)
+    for lean in (0, 1):           # the two-kernel paths: D,E,B,H resident / D,B resident (the default is the fused kernel)
+        _run("fdtd3d", dict(env, FDTD3D_PRECISION=64, FDTD3D_FUSED=0, FDTD3D_LEAN=lean), str(tmp_path))
+        _compare_dir(str(tmp_path / "output_3d"), fx)
     _run("fdtd3d", dict(env, FDTD3D_PRECISION=32), str(tmp_path))
     # fp32: same files, values within the stated drift (relative L2 <= 1e-6 of the field's norm)
     def values(path, opener):
@@ -64,6 +65,26 @@ def test_fdtd3d_driver_full_storage_and_fp32(tmp_path):
         got = values(str(tmp_path / "output_3d" / n), lambda p: open(p, "rb"))
         want = values(os.path.join(fx, n + ".gz"), lambda p: gzip.open(p, "rb"))
         assert util.rel_l2(got, want) < 1e-6
+
+
+def test_fdtd3d_driver_binary_vti(tmp_path):
+    """Opt-in raw appended VTI: the Float32 payload equals the reference's ASCII values rounded to fp32."""
+    fx = os.path.join(util.GOLDEN, "run3d")
+    meta = json.load(open(os.path.join(fx, "meta.json")))
+    _run("fdtd3d", dict(FDTD3D_NX=meta["N"][0], FDTD3D_NY=meta["N"][1], FDTD3D_NZ=meta["N"][2], FDTD3D_NPML=meta["npml"][0],
+                        FDTD3D_STEPS=meta["steps"], FDTD3D_PRECISION=64, FDTD3D_BINARY_VTI=1), str(tmp_path))
+    cells = meta["N"][0] * meta["N"][1] * meta["N"][2]
+    for n in ("Ex_t00040.vti", "E_mag_t00020.vti", "E_mag_rms_t00040.vti"):
+        raw = open(str(tmp_path / "output_3d" / n), "rb").read()
+        head, rest = raw.split(b'<AppendedData encoding="raw">\n   _', 1)
+        assert b'header_type="UInt64"' in head and b'type="Float32"' in head and b'format="appended" offset="0"' in head
+        nbytes = int(np.frombuffer(rest[:8], dtype="<u8")[0])
+        assert nbytes == 4 * cells
+        got = np.frombuffer(rest[8:8 + nbytes], dtype="<f4")
+        assert rest[8 + nbytes:] == b"\n  </AppendedData>\n</VTKFile>\n"
+        txt = gzip.open(os.path.join(fx, n + ".gz"), "rb").read().decode()
+        want = np.array(txt.split('NumberOfComponents="1">\n')[1].split("        </DataArray>")[0].split(), dtype=np.float64)
+        assert np.array_equal(got, want.astype(np.float32))
 
 
 def test_fdtd2d_driver_writes_the_reference_files(tmp_path):

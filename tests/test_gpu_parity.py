@@ -273,3 +273,29 @@ def test_device_probe_series_2d():
     series = eng.probe_read()
     assert series.shape == (meta["steps"], 1)
     util.assert_equal_arrays(series[:, 0], extra["probe"], "2-D device probe series")
+
+
+@pytest.mark.parametrize("z_range", [None, (30, 71)])
+def test_reference_materials_on_device_equal_host_generator(z_range):
+    """FDTD3D::setupMaterials evaluated on the device == the host restatement (itself pinned to the
+    compiled reference in tests/test_oracle_ref.py), bit for bit, sphere surface included."""
+    from fdtd_amd import setup as fs
+    N = (96, 90, 100)
+    d = (1053e-9 / 20,) * 3
+    K = po.consts()
+    eng = fdtd_amd.Engine3D(N, (0,) * 6, d, d[0] / (2 * K["c0"]), K["mu0"], 20, 1, precision=64, z_range=z_range)
+    eng.fill_reference_materials()
+    want = fs.default_materials3d(N, d)
+    assert len({float(v) for v in np.unique(want[0])}) > 2          # the blend values of the sphere surface are present
+    for c in range(3):
+        w = want[c].copy()
+        if w.shape[0] == N[0] + 1:
+            w[-1] = 0                                               # unstored wall column
+        got = np.full(w.size, np.nan)
+        eng.get(po.EPS_X + c, out=got)
+        got = got.reshape(w.shape)
+        if z_range is not None:
+            lo, hi = z_range
+            util.assert_equal_arrays(got[:, :, lo:hi], w[:, :, lo:hi], f"device eps component {c}, slab")
+        else:
+            util.assert_equal_arrays(got, w, f"device eps component {c}")
