@@ -4,7 +4,7 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json config 4/5): 1024 x 1024 x (1024 * N) cells, heterogeneous eps and mu
+Workload: 1024 x 1024 x (1024 * N) cells, heterogeneous eps and mu
 grids (synthetic, counter hash), 20-layer CPML on all six faces, Gaussian sheet current source,
 fp32, one z-slab of 1024 layers per GPU, one ghost plane of tangential D (E) and B (H) exchanged
 per step half.  One "step" = E-half + H-half over the whole grid, by default in ONE fused kernel per

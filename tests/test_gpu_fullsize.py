@@ -1,4 +1,4 @@
-"""Properties at sizes no CPU oracle reaches (BASELINE configs 3-5 geometry, reduced step counts).
+"""Properties at sizes no CPU oracle reaches (the 512^3 cavity and the 1024-wide material/CPML workloads, reduced step counts).
 
 Bit-exactness is carried by order-independent checksums (value bits mixed with the cell index):
 lean storage == full storage, slabs == whole grid, launch shape (planes per workgroup, tile order)
@@ -35,7 +35,7 @@ def make(N, npml, mode, has_mu, z_range=None, steps=64, dipole=False):
 
 
 def test_vacuum_cavity_512_lean_equals_full_and_stays_bounded():
-    """BASELINE config 3: 512^3 vacuum cavity (no CPML), dipole source."""
+    """512^3 vacuum cavity (no CPML), dipole source."""
     N, steps = (512, 512, 512), 24
     sums = {}
     for mode in (E.MODE_FULL, E.MODE_LEAN):
@@ -49,7 +49,7 @@ def test_vacuum_cavity_512_lean_equals_full_and_stays_bounded():
 
 
 def test_hetero_cpml_slabs_equal_whole_grid_384():
-    """BASELINE config 4 geometry (eps/mu grids, 20-layer CPML) at 384x384x512: 4 slabs == whole grid,
+    """The material-grid workload (eps/mu grids, 20-layer CPML) at 384x384x512: 4 slabs == whole grid,
     and the launch shape does not change a bit."""
     N, steps = (384, 384, 512), 12
     whole = make(N, (20,) * 6, E.MODE_LEAN, True, steps=steps)

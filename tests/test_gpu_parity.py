@@ -190,7 +190,7 @@ def test_fp32_engine_equals_fp32_twin_2d():
 
 
 def test_pec512_point_source_2d():
-    """BASELINE config 1 geometry on the GPU: snapshots, probe series and sums == reference (fp64)."""
+    """The 512x512 PEC point-source case on the GPU: snapshots, probe series and sums == reference (fp64)."""
     meta, ins, outs, extra = util.load_fixture("g5_2d_pec512")
     eng = engine2d_from_meta(meta, 64)
     util.feed(eng, ins)

@@ -76,7 +76,7 @@ def test_twin32_close_to_reference_2d_slab():
 
 
 def test_twin64_matches_reference_2d_pec512():
-    """BASELINE config 1: 512x512, PEC walls, point source, 2000 steps on the CPU path."""
+    """512x512, PEC walls, point source, 2000 steps on the CPU path."""
     meta, ins, outs, extra = util.load_fixture("g5_2d_pec512")
     tw = util.twin2d_from_meta(meta, 64)
     util.feed(tw, ins)

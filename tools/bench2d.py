@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Secondary benchmark: fdtd2d 8192 x 8192, 20-layer CPML on four sides, the reference's Lorentz slab
-(BASELINE config 2) on one MI355X.  Prints one JSON line; not the graded headline (bench.py is)."""
+on one MI355X.  Prints one JSON line; not the graded headline (bench.py is)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
