@@ -40,8 +40,20 @@ def cpu_baseline():
     from oracle import pyoracle as po
     ref_lib = os.path.join(ROOT, "oracle", "_ref", "libref3d.so")
     if os.path.exists(ref_lib):
-        # the unmodified reference solver compiled from its own sources: its default 200^3 problem
-        r = po.Ref3D()
+        # the unmodified reference solver compiled from its own sources: its default 200^3 problem.
+        # Its constructor prints a banner on stdout; this program's stdout carries exactly one JSON line,
+        # so the banner goes to stderr.
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            r = po.Ref3D()
+        finally:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)       # the banner sits in C stdio's buffer when stdout is a pipe
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
         r.step(0, 2)
         steps = 20
         t0 = time.perf_counter()
