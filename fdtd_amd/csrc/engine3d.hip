@@ -350,12 +350,13 @@ struct Engine3 : fdtd3d_engine {
         // the step kernels by up to 10 % (measured: the same binary and virtual address run a 1024^3 step
         // in 18.1, 18.9 or 20.0 ms, cycling with every free + allocate, across processes).  For large
         // grids the arena is therefore placed a few times, each placement timed with four source-free
-        // steps on the zero state (which they leave unchanged), until one is as fast as the best seen.
-        int tries = arena_cap >= ((size_t)8 << 30) ? 6 : 1;
+        // steps on the zero state (which they leave unchanged); after three placements the first one in
+        // the fast third of the range seen so far is kept (an earlier placement cannot be returned to).
+        int tries = arena_cap >= ((size_t)8 << 30) ? 8 : 1;
         if (const char* e = getenv("FDTD_PLACEMENT_TRIES")) { int v = atoi(e); if (v >= 1 && v <= 16) tries = v; }
         int explore = 3;                 // placements timed before the first may be accepted
         if (const char* e = getenv("FDTD_PLACEMENT_EXPLORE")) { int v = atoi(e); if (v >= 1 && v <= 16) explore = v; }
-        double best = 1e300;
+        double best = 1e300, worst = 0;
         for (int t = 0;; ++t) {
             arena_used = 0; bytes = 0;
             FDTD_HIP(hipMalloc((void**)&arena, arena_cap));
@@ -365,9 +366,9 @@ struct Engine3 : fdtd3d_engine {
             double ms = 0;
             if ((rc = probe(&ms))) return rc;
             const bool explored = t + 1 >= explore || t + 1 >= tries;
-            best = std::min(best, ms);
+            best = std::min(best, ms); worst = std::max(worst, ms);
             placement_log.push_back(ms);
-            if ((explored && ms <= best * 1.01) || t + 1 >= tries) break;
+            if ((explored && ms <= std::max(best * 1.005, best + 0.35 * (worst - best))) || t + 1 >= tries) break;
             FDTD_HIP(hipFree(arena));
             allocs.clear(); arena = nullptr;
         }
