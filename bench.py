@@ -140,6 +140,8 @@ def main():
     eng.fill_materials(1234, K["eps0"], 4.0 * K["eps0"], K["mu0"], 2.0 * K["mu0"])
 
     stepper = slab.make_gpu_stepper(eng, rank, world) if world > 1 else None
+    if stepper is not None:
+        stepper.prime()          # RCCL sets its point-to-point channels up here, not in a timed step
 
     def run(n0, count):
         if stepper is None:

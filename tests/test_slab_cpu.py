@@ -123,6 +123,7 @@ def _fused_worker(rank, world, port, Nz, steps, out):
     eng = FusedLine(Nz, z_lo, z_hi, kJ=3)
     xs = [slab.HaloExchange(rank, world, [H[eng.nzl:eng.nzl + 1]], [H[0:1]], [E[1:2]], [E[eng.nzl + 1:eng.nzl + 2]]) for E, H in eng.bufs]
     st = slab.FusedSlabStepper(eng, xs)
+    st.prime()
     st.run(0, steps)
     st.finish()
     owned_e = eng.E[1:eng.nzl + 1 + (1 if eng.last else 0)].clone()
@@ -143,6 +144,7 @@ def _worker(rank, world, port, Nz, steps, out):
     eng = Line(Nz, z_lo, z_hi, kJ=3)
     x = slab.HaloExchange(rank, world, [eng.H[eng.nzl:eng.nzl + 1]], [eng.H[0:1]], [eng.E[1:2]], [eng.E[eng.nzl + 1:eng.nzl + 2]])
     st = slab.SlabStepper(eng, x)
+    st.prime()
     st.run(0, steps)
     st.finish()
     owned_e = eng.E[1:eng.nzl + 1 + (1 if eng.last else 0)].clone()
