@@ -746,7 +746,7 @@ struct Engine3 : fdtd3d_engine {
     // One launch per time step: D and B cross HBM once.  On a slab the lowest chunk of planes can be
     // launched first (EDGE) so that its D planes travel while the rest (INTERIOR) is computed; the
     // buffers change roles when the first part of a step is launched.
-    bool mid_step = false;
+    int phase = 0;                   // 0 between steps, 1 after EDGE, 2 after EDGE + TOP
     int flips = 0;
     int parity() override { return flips & 1; }
     int step(int n, hipStream_t s) override {
@@ -757,19 +757,25 @@ struct Engine3 : fdtd3d_engine {
     // B of the top layer of a slab that has another one above it (no-op on the last slab)
     int fused_top(hipStream_t s) override {
         if (!fused) return fail(FDTD_ERR_STATE, "fused stepping needs an engine created with FDTD3D_MODE_FUSED");
-        if (mid_step) return fail(FDTD_ERR_STATE, "fused: the step's INTERIOR part has not been launched");
+        if (phase == 1) return fail(FDTD_ERR_STATE, "fused: the part holding the top layer (TOP or INTERIOR) has not been launched");
         return last_rank ? FDTD_OK : half_h(FDTD3D_PART_EDGE, s);
     }
     int fused_part(int n, int part, hipStream_t s) override {
         if (!fused) return fail(FDTD_ERR_STATE, "fused stepping needs an engine created with FDTD3D_MODE_FUSED");
-        // EDGE only has to produce layer z_lo early; a short chunk keeps that poorly filled launch small
-        const int lo = 1, hi = last_rank ? nzp : nzp - 1, cut = std::min(lo + std::min(chunk, 8), hi);
+        // EDGE only has to produce layer z_lo early, TOP only the top layer: short chunks keep those poorly
+        // filled launches small
+        const int lo = 1, hi = last_rank ? nzp : nzp - 1, few = std::min(chunk, 8);
+        const int cut = std::min(lo + few, hi), cut2 = std::max(cut, hi - few);
         int kl0, kl1;
         if (part == FDTD3D_PART_ALL) { kl0 = lo; kl1 = hi; }
         else if (part == FDTD3D_PART_EDGE) { kl0 = lo; kl1 = cut; }
-        else if (part == FDTD3D_PART_INTERIOR) { kl0 = cut; kl1 = hi; }
+        else if (part == FDTD3D_PART_TOP) { kl0 = cut2; kl1 = hi; }
+        else if (part == FDTD3D_PART_INTERIOR) { kl0 = cut; kl1 = phase == 2 ? cut2 : hi; }
         else return fail(FDTD_ERR_ARG, "fused: bad part %d", part);
-        if ((part == FDTD3D_PART_INTERIOR) != mid_step) return fail(FDTD_ERR_STATE, "fused: a step is EDGE followed by INTERIOR, or ALL");
+        const bool first_of_step = part == FDTD3D_PART_ALL || part == FDTD3D_PART_EDGE;
+        if (first_of_step ? phase != 0 : (part == FDTD3D_PART_TOP ? phase != 1 : phase == 0))
+            return fail(FDTD_ERR_STATE, "fused: a step is ALL, or EDGE [TOP] INTERIOR in this order");
+        const bool mid_step = !first_of_step;
         K3<T> a = args();
         a.src_on = (n >= 0 && n < (int)wf.size()) ? 1 : 0;
         a.jx = a.src_on ? a.dt * wf[n] : (T)0;
@@ -793,14 +799,14 @@ struct Engine3 : fdtd3d_engine {
             timer.end(s);
             FDTD_HIP(hipGetLastError());
         }
-        if (part != FDTD3D_PART_INTERIOR) {
+        if (first_of_step) {
             for (int c = 0; c < 3; ++c) {
                 std::swap(fld[c], alt[c]); std::swap(fld[6 + c], alt[6 + c]);
                 for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) std::swap(phE[c][ax][sd], phE2[c][ax][sd]);
             }
             ++flips;
         }
-        mid_step = part == FDTD3D_PART_EDGE;
+        phase = part == FDTD3D_PART_EDGE ? 1 : (part == FDTD3D_PART_TOP ? 2 : 0);
         return FDTD_OK;
     }
 

@@ -23,7 +23,7 @@ DX, DY, DZ, EX, EY, EZ, BX, BY, BZ, HX, HY, HZ = range(12)
 EPS_X, EPS_Y, EPS_Z, MU_X, MU_Y, MU_Z = range(12, 18)
 PHI_E, PHI_M, TAB, JX_MAG, JX_WF = 100, 200, 300, 400, 401
 MODE_FULL, MODE_LEAN, MODE_FUSED = 0, 1, 2
-PART_ALL, PART_EDGE, PART_INTERIOR = 0, 1, 2
+PART_ALL, PART_EDGE, PART_INTERIOR, PART_TOP = 0, 1, 2, 3
 HALO_SEND_UP, HALO_RECV_LO, HALO_SEND_DOWN, HALO_RECV_HI = 0, 1, 2, 3
 
 D2_DY, D2_EY, D2_EY_N1, D2_EY_N2, D2_SEY, D2_SEY_N1, D2_SEY_N2 = range(7)

@@ -19,7 +19,7 @@ from __future__ import annotations
 
 from typing import List, Sequence, Tuple
 
-PART_ALL, PART_EDGE, PART_INTERIOR = 0, 1, 2
+PART_ALL, PART_EDGE, PART_INTERIOR, PART_TOP = 0, 1, 2, 3
 
 
 def partition(Nz: int, world: int) -> List[Tuple[int, int]]:
@@ -101,10 +101,10 @@ class FusedSlabStepper:
 
     `engine` needs fused(n, part), fused_top() and parity(); `exchanges` holds one HaloExchange per
     buffer parity (the planes alias whichever D/B buffers are current after the step's first launch).
-    Per step: the lowest chunk of planes first, its D planes start travelling down, the rest of the
-    slab is computed meanwhile; the top layer's B, which needs the upper neighbour's new D, is
-    finished by the single-plane H kernel once that plane has arrived, and then travels up for the
-    next step's lowest chunk.
+    Per step: the lowest planes first, so that D of layer z_lo starts travelling down; then the highest
+    planes; as soon as the upper neighbour's D plane is there, the single-plane H kernel finishes the top
+    layer's B, which starts travelling up; the bulk of the slab is computed while both exchanges are in
+    flight.  The next step's lowest planes wait for the B plane from below.
     """
 
     def __init__(self, engine, exchanges: Sequence[HaloExchange], stream=None):
@@ -117,10 +117,11 @@ class FusedSlabStepper:
         e.fused(n, PART_EDGE, s)
         x = self.xs[e.parity() % len(self.xs)]
         pending_d = x.start_down()
-        e.fused(n, PART_INTERIOR, s)
+        e.fused(n, PART_TOP, s)
         HaloExchange.wait(pending_d)                 # new D of layer z_hi
         e.fused_top(s)
         self._pending_b = x.start_up()
+        e.fused(n, PART_INTERIOR, s)
         if getattr(e, "probe_count", 0):
             e.probe_record(s)
 

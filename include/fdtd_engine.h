@@ -127,6 +127,7 @@ int fdtd3d_step(fdtd3d_handle h, int n0, int count, void* stream);
 #define FDTD3D_PART_ALL 0
 #define FDTD3D_PART_EDGE 1       /* E-half: lowest owned layer; H-half: highest owned layer */
 #define FDTD3D_PART_INTERIOR 2   /* the rest                                                 */
+#define FDTD3D_PART_TOP 3        /* fdtd3d_fused only: the highest owned planes               */
 int fdtd3d_half_e(fdtd3d_handle h, int n, int part, void* stream);
 int fdtd3d_half_h(fdtd3d_handle h, int part, void* stream);
 
@@ -134,8 +135,10 @@ int fdtd3d_half_h(fdtd3d_handle h, int part, void* stream);
  * cell for cell in the same operation order), reading the current D, B and D-side CPML buffers
  * and writing the other set; the two sets change roles when the first part of a step is launched.
  *   PART_ALL       the whole slab.
- *   PART_EDGE      the lowest planes (at most 8), so that D of layer z_lo can
- *                  travel down while PART_INTERIOR, which must follow, computes the rest.
+ *   PART_EDGE      the lowest planes (at most 8), so that D of layer z_lo can travel down early.
+ *   PART_TOP       optional, after EDGE: the highest planes (at most 8), so that the top layer can be
+ *                  finished (fdtd3d_fused_top) and its B sent up while the bulk is still running.
+ *   PART_INTERIOR  everything the step's earlier parts left; ends the step.
  * A slab below another one leaves B of its top layer z_hi-1 unchanged: once the upper
  * neighbour's D has arrived in the high ghost plane, fdtd3d_fused_top() finishes it with the
  * single-plane H kernel (a no-op on the slab that holds k = Nz).

@@ -135,8 +135,10 @@ def test_fused_slabs_equal_whole_grid_384():
             for c in (0, 1):
                 cur[r - 1][E.HALO_RECV_HI][c].copy_(cur[r][E.HALO_SEND_DOWN][c])
         for e in engs:
-            e.fused(n, E.PART_INTERIOR)
+            e.fused(n, E.PART_TOP)
+        for e in engs:
             e.fused_top()
+            e.fused(n, E.PART_INTERIOR)
         for r in range(3):
             for c in (0, 1):
                 cur[r + 1][E.HALO_RECV_LO][c].copy_(cur[r][E.HALO_SEND_UP][c])

@@ -93,7 +93,7 @@ def test_fused_ragged_shapes_3d(prec, N, npml, rows, chunk):
             util.assert_equal_arrays(eng.get(id_), tw.get(id_), f"N={N} array {id_}")
 
 
-def run_fused_slabs(meta, ins, parts, prec, steps, chunk, has_mu=False, extra_feed=None):
+def run_fused_slabs(meta, ins, parts, prec, steps, chunk, has_mu=False, extra_feed=None, use_top=True):
     """Several FUSED slab engines in one process; ghost planes move by device copies exactly where
     the send/recv pairs sit in fdtd_amd.slab.FusedSlabStepper."""
     from fdtd_amd import engine as E
@@ -112,23 +112,32 @@ def run_fused_slabs(meta, ins, parts, prec, steps, chunk, has_mu=False, extra_fe
         for r in range(1, len(engs)):
             for c in (0, 1):
                 cur[r - 1][E.HALO_RECV_HI][c].copy_(cur[r][E.HALO_SEND_DOWN][c])
-        for e in engs:
-            e.fused(n, E.PART_INTERIOR)
-        for e in engs:
-            e.fused_top()
+        if use_top:          # the stepper's order: top planes, top layer finished, bulk last
+            for e in engs:
+                e.fused(n, E.PART_TOP)
+            for e in engs:
+                e.fused_top()
+            for e in engs:
+                e.fused(n, E.PART_INTERIOR)
+        else:
+            for e in engs:
+                e.fused(n, E.PART_INTERIOR)
+            for e in engs:
+                e.fused_top()
         for r in range(len(engs) - 1):
             for c in (0, 1):
                 cur[r + 1][E.HALO_RECV_LO][c].copy_(cur[r][E.HALO_SEND_UP][c])
     return engs
 
 
+@pytest.mark.parametrize("use_top", [True, False])
 @pytest.mark.parametrize("name,world,chunk", [("g1_3d_cpml", 2, 8), ("g3_3d_hetero", 3, 2), ("g2_3d_cavity", 4, 3), ("g3_3d_hetero", 8, 16)])
-def test_fused_slabs_reproduce_reference(name, world, chunk):
+def test_fused_slabs_reproduce_reference(name, world, chunk, use_top):
     from fdtd_amd import slab
     from tests.test_gpu_slabs import assemble
     meta, ins, outs, _ = util.load_fixture(name)
     steps = meta["steps"]
-    engs = run_fused_slabs(meta, ins, slab.partition(meta["N"][2], world), 64, steps, chunk)
+    engs = run_fused_slabs(meta, ins, slab.partition(meta["N"][2], world), 64, steps, chunk, use_top=use_top)
     for (step, id_), want in outs.items():
         if step == steps:
             util.assert_equal_arrays(assemble(engs, id_), want, f"{name} x{world} fused slabs, array {id_}")
@@ -150,9 +159,17 @@ def test_fused_part_order_is_checked():
     eng = fdtd_amd.Engine3D((16, 16, 16), (0,) * 6, (1e-7,) * 3, 1e-16, K["mu0"], 4, 3, precision=32, mode=MODE_FUSED, z_range=(0, 8))
     with pytest.raises(fdtd_amd.engine.EngineError):
         eng.fused(0, fdtd_amd.engine.PART_INTERIOR)
+    with pytest.raises(fdtd_amd.engine.EngineError):
+        eng.fused(0, fdtd_amd.engine.PART_TOP)
     eng.fused(0, fdtd_amd.engine.PART_EDGE)
     with pytest.raises(fdtd_amd.engine.EngineError):
         eng.fused(0, fdtd_amd.engine.PART_EDGE)
+    with pytest.raises(fdtd_amd.engine.EngineError):
+        eng.fused_top()                                    # the top layer's part has not run yet
+    eng.fused(0, fdtd_amd.engine.PART_TOP)
+    eng.fused_top()
+    with pytest.raises(fdtd_amd.engine.EngineError):
+        eng.fused(0, fdtd_amd.engine.PART_TOP)
     eng.fused(0, fdtd_amd.engine.PART_INTERIOR)
     lean = fdtd_amd.Engine3D((16, 16, 16), (0,) * 6, (1e-7,) * 3, 1e-16, K["mu0"], 4, 3, precision=32, mode=fdtd_amd.engine.MODE_LEAN)
     with pytest.raises(fdtd_amd.engine.EngineError):

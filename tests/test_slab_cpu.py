@@ -72,12 +72,13 @@ class FusedLine(Line):
     def __init__(self, Nz, z_lo, z_hi, kJ):
         super().__init__(Nz, z_lo, z_hi, kJ)
         self.bufs = [(self.E, self.H), (torch.zeros_like(self.E), torch.zeros_like(self.H))]
-        self.cur, self.mid = 0, False
+        self.cur, self.phase = 0, 0
 
     def parity(self):
         return self.cur
 
     def fused_top(self, stream=None):
+        assert self.phase != 1
         if not self.last:
             self.half_h(slab.PART_EDGE)
 
@@ -92,10 +93,14 @@ class FusedLine(Line):
 
     def fused(self, n, part, stream=None):
         lo, hi = 1, (self.nzl + 2 if self.last else self.nzl + 1)
-        cut = min(lo + min(self.chunk, 3), hi)          # the engine also uses a shorter chunk for EDGE
-        kl0, kl1 = {slab.PART_ALL: (lo, hi), slab.PART_EDGE: (lo, cut), slab.PART_INTERIOR: (cut, hi)}[part]
-        assert (part == slab.PART_INTERIOR) == self.mid
-        old, new = (1 - self.cur, self.cur) if self.mid else (self.cur, 1 - self.cur)
+        few = min(self.chunk, 3)                              # the engine also uses short EDGE / TOP parts
+        cut = min(lo + few, hi)
+        cut2 = max(cut, hi - few)
+        first = part in (slab.PART_ALL, slab.PART_EDGE)
+        assert (self.phase == 0) if first else (self.phase == 1 if part == slab.PART_TOP else self.phase != 0)
+        kl0, kl1 = {slab.PART_ALL: (lo, hi), slab.PART_EDGE: (lo, cut), slab.PART_TOP: (cut2, hi),
+                    slab.PART_INTERIOR: (cut, cut2 if self.phase == 2 else hi)}[part]
+        old, new = (self.cur, 1 - self.cur) if first else (1 - self.cur, self.cur)
         (Eo, Ho), (En, Hn) = self.bufs[old], self.bufs[new]
         for cb in range(kl0, kl1, self.chunk):
             ce = min(cb + self.chunk, kl1)
@@ -110,10 +115,10 @@ class FusedLine(Line):
                 e_prev = e
                 if not self.last and kl == hi - 1:
                     Hn[kl] = Ho[kl]
-        if part != slab.PART_INTERIOR:
+        if first:
             self.cur = 1 - self.cur
             self.E, self.H = self.bufs[self.cur]
-        self.mid = part == slab.PART_EDGE
+        self.phase = 1 if part == slab.PART_EDGE else (2 if part == slab.PART_TOP else 0)
 
 
 def _fused_worker(rank, world, port, Nz, steps, out):
