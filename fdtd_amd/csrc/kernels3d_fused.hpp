@@ -340,8 +340,10 @@ __global__ void __launch_bounds__(kLanes * MAXW) __attribute__((amdgpu_waves_per
         }
 
         // a slab below another one leaves B of its top layer to the kernel that runs once the upper
-        // neighbour's D has arrived; the new buffer only receives the old values here
-        if (a.copy_top && kl == a.kl_stop - 1 && row_ok && !halo_row) {
+        // neighbour's D has arrived; the new buffer only receives the old values here -- from the launch
+        // that owns the layer, not from a chunk below that merely revisits it as its closing plane (that
+        // chunk may run after the layer has been finished)
+        if (a.copy_top && kl == a.kl_stop - 1 && kl < kle && row_ok && !halo_row) {
             stg_nt<T, V>(ap->Bn[0] + ro, lo, bo[0]); stg_nt<T, V>(ap->Bn[1] + ro, lo, bo[1]); stg_nt<T, V>(ap->Bn[2] + ro, lo, bo[2]);
         }
 

@@ -63,6 +63,13 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise EngineError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950); there is no fallback path")
+        # PyTorch ships its own copy of the HIP runtime; a process that hands device memory to
+        # torch.distributed must not end up with two of them, so torch (if present) loads its copy first
+        # and this library then binds to that one.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.fdtd_last_error.restype = C.c_char_p
         L.fdtd_engine_version.restype = C.c_char_p

@@ -213,3 +213,108 @@ def test_probe_on_fused_slabs_matches_reference_series():
             for c in (0, 1):
                 cur[r + 1][E.HALO_RECV_LO][c].copy_(cur[r][E.HALO_SEND_UP][c])
     util.assert_equal_arrays(owners[0].probe_read()[:, 0], extra["probe"], "probe series on fused slabs")
+
+
+def _random_case(rng):
+    N = tuple(int(v) for v in rng.integers(4, 41, size=3))
+    if rng.random() < 0.3:
+        N = (int(rng.integers(250, 300)), N[1], N[2])             # more than one x tile
+    npml = []
+    for a in range(3):
+        lo, hi = (int(rng.integers(0, 7)) if rng.random() < 0.7 else 0 for _ in range(2))
+        while lo + hi >= N[a] - 1:
+            lo, hi = lo // 2, hi // 2
+        npml += [lo, hi]
+    if npml[0] and npml[1] and (N[0] - npml[1]) // 4 * 4 < (npml[0] + 1 + 3) // 4 * 4:
+        npml[1] = 0                                                 # the two x strips must stay disjoint
+    return N, tuple(npml), int(rng.choice([32, 64])), bool(rng.random() < 0.5), int(rng.integers(2, 17)), int(rng.integers(1, 12))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fused_random_configurations_equal_twin(seed):
+    """Random grid shapes, CPML layer counts (zero included, per face), precision, mu grid and
+    workgroup shape: the fused kernel must agree with the CPU twin bit for bit on every field and
+    every CPML auxiliary array."""
+    rng = np.random.default_rng(1000 + seed)
+    N, npml, prec, has_mu, rows, chunk = _random_case(rng)
+    K = po.consts()
+    d = (5e-8, 6e-8, 7e-8)
+    dt = 5e-8 / (2 * K["c0"])
+    steps = 13
+    kJ = int(rng.integers(0, N[2] + 1))
+    eng = fdtd_amd.Engine3D(N, npml, d, dt, K["mu0"], kJ, steps, precision=prec, mode=MODE_FUSED, has_mu=has_mu)
+    eng.tune(chunk, int(rng.integers(0, 2)), rows)
+    tw = po.Twin3D(prec, N, npml, d, dt, K["mu0"], kJ, steps, has_mu)
+    wf = rng.standard_normal(steps)
+    mag = rng.random((N[0], N[1] + 1))
+    for be in (eng, tw):
+        for a in range(3):
+            for s in range(2):
+                if npml[a * 2 + s]:
+                    tabs = po.cpml_face(npml[a * 2 + s], s, d[a], d[a], dt)
+                    for k in range(6):
+                        be.set(po.tab_id(a, s, k), tabs[k])
+        be.set(po.JX_WF, wf)
+        be.set(po.JX_MAG, mag)
+        be.fill_materials(seed, K["eps0"], 4 * K["eps0"], K["mu0"], 3 * K["mu0"])
+    eng.step(0, steps)
+    tw.step(0, steps)
+    for id_ in po.FIELDS3D + po.ALL_PHI3D:
+        if eng.size(id_):
+            util.assert_equal_arrays(eng.get(id_), tw.get(id_), f"seed {seed}: N={N} npml={npml} fp{prec} mu={has_mu} rows={rows} chunk={chunk}, array {id_}")
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fused_random_slab_partitions_equal_twin(seed):
+    """Random uneven z partitions (single-layer slabs included) of random small problems, stepped in the
+    slab order EDGE, TOP, top layer, INTERIOR with device copies for the exchanges: == the twin."""
+    from fdtd_amd import engine as E
+    from tests.test_gpu_slabs import assemble
+    rng = np.random.default_rng(7000 + seed)
+    N, npml, prec, has_mu, rows, chunk = _random_case(rng)
+    N = (N[0], N[1], max(N[2], 12))
+    cuts = sorted(set(int(v) for v in rng.integers(1, N[2], size=int(rng.integers(1, 4)))))
+    parts = list(zip([0] + cuts, cuts + [N[2]]))
+    K = po.consts()
+    d = (5e-8, 6e-8, 7e-8)
+    dt = 5e-8 / (2 * K["c0"])
+    steps = 9
+    kJ = int(rng.integers(0, N[2] + 1))
+    engs = [fdtd_amd.Engine3D(N, npml, d, dt, K["mu0"], kJ, steps, precision=prec, mode=MODE_FUSED, has_mu=has_mu, z_range=p) for p in parts]
+    tw = po.Twin3D(prec, N, npml, d, dt, K["mu0"], kJ, steps, has_mu)
+    wf = rng.standard_normal(steps)
+    mag = rng.random((N[0], N[1] + 1))
+    for be in engs + [tw]:
+        for a in range(3):
+            for s in range(2):
+                if npml[a * 2 + s]:
+                    tabs = po.cpml_face(npml[a * 2 + s], s, d[a], d[a], dt)
+                    for k in range(6):
+                        be.set(po.tab_id(a, s, k), tabs[k])
+        be.set(po.JX_WF, wf)
+        be.set(po.JX_MAG, mag)
+        be.fill_materials(seed, K["eps0"], 4 * K["eps0"], K["mu0"], 3 * K["mu0"])
+    for e in engs:
+        e.tune(chunk, 1, rows)
+    pl = [[{w: [E.halo_tensor(e, w, c, par) for c in (0, 1)] for w in range(4)} for par in (0, 1)] for e in engs]
+    R = len(engs)
+    for n in range(steps):
+        for e in engs:
+            e.fused(n, E.PART_EDGE)
+        cur = [pl[r][engs[r].parity()] for r in range(R)]
+        for r in range(1, R):
+            for c in (0, 1):
+                cur[r - 1][E.HALO_RECV_HI][c].copy_(cur[r][E.HALO_SEND_DOWN][c])
+        for e in engs:
+            e.fused(n, E.PART_TOP)
+        for e in engs:
+            e.fused_top()
+        for e in engs:
+            e.fused(n, E.PART_INTERIOR)
+        for r in range(R - 1):
+            for c in (0, 1):
+                cur[r + 1][E.HALO_RECV_LO][c].copy_(cur[r][E.HALO_SEND_UP][c])
+    tw.step(0, steps)
+    for id_ in po.FIELDS3D + po.ALL_PHI3D:
+        if engs[0].size(id_):
+            util.assert_equal_arrays(assemble(engs, id_), tw.get(id_), f"seed {seed}: N={N} npml={npml} parts={parts} fp{prec} mu={has_mu}, array {id_}")

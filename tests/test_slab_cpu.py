@@ -113,7 +113,7 @@ class FusedLine(Line):
                 if kl > cb and self.z_lo - 1 + (kl - 1) < self.Nz:
                     Hn[kl - 1] = Ho[kl - 1] + 0.5 * (e - e_prev)
                 e_prev = e
-                if not self.last and kl == hi - 1:
+                if not self.last and kl == hi - 1 and kl < ce:     # only the chunk that owns the top layer carries it over
                     Hn[kl] = Ho[kl]
         if first:
             self.cur = 1 - self.cur
@@ -121,11 +121,12 @@ class FusedLine(Line):
         self.phase = 1 if part == slab.PART_EDGE else (2 if part == slab.PART_TOP else 0)
 
 
-def _fused_worker(rank, world, port, Nz, steps, out):
+def _fused_worker(rank, world, port, Nz, steps, out, chunk=4):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     z_lo, z_hi = slab.partition(Nz, world)[rank]
     eng = FusedLine(Nz, z_lo, z_hi, kJ=3)
+    eng.chunk = chunk
     xs = [slab.HaloExchange(rank, world, [H[eng.nzl:eng.nzl + 1]], [H[0:1]], [E[1:2]], [E[eng.nzl + 1:eng.nzl + 2]]) for E, H in eng.bufs]
     st = slab.FusedSlabStepper(eng, xs)
     st.prime()
@@ -195,15 +196,15 @@ def test_fused_line_equals_half_steps():
     assert torch.equal(fl.E, ref.E) and torch.equal(fl.H, ref.H)
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_fused_exchange_reproduces_single_rank(tmp_path, world):
+@pytest.mark.parametrize("world,chunk", [(2, 4), (3, 4), (2, 1)])
+def test_fused_exchange_reproduces_single_rank(tmp_path, world, chunk):
     Nz, steps = 23, 41
     ref = Line(Nz, 0, Nz, kJ=3)
     for n in range(steps):
         ref.half_e(n, slab.PART_ALL)
         ref.half_h(slab.PART_ALL)
     out = str(tmp_path / "fslab")
-    mp.spawn(_fused_worker, args=(world, _free_port(), Nz, steps, out), nprocs=world, join=True)
+    mp.spawn(_fused_worker, args=(world, _free_port(), Nz, steps, out, chunk), nprocs=world, join=True)
     e, h = np.load(out + "_e.npy"), np.load(out + "_h.npy")
     assert np.array_equal(e, ref.E[1:Nz + 2].numpy())
     assert np.array_equal(h, ref.H[1:Nz + 1].numpy())
