@@ -299,3 +299,92 @@ def test_reference_materials_on_device_equal_host_generator(z_range):
             util.assert_equal_arrays(got[:, :, lo:hi], w[:, :, lo:hi], f"device eps component {c}, slab")
         else:
             util.assert_equal_arrays(got, w, f"device eps component {c}")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_configurations_2d_equal_twin(seed):
+    """Random 2-D shapes (one to three x tiles), per-side CPML counts, source cell, precision, rows per
+    wave, and Lorentz coefficients that are non-zero only in a random band of columns or rows -- so that
+    dispersive and non-dispersive tiles meet inside the grid: every field, history and CPML array must
+    equal the twin's bit for bit."""
+    rng = np.random.default_rng(500 + seed)
+    Nx = int(rng.choice([rng.integers(8, 60), rng.integers(250, 270), rng.integers(500, 700)]))
+    Nz = int(rng.integers(6, 50))
+    npml = [int(rng.integers(0, 6)) if rng.random() < 0.7 else 0 for _ in range(4)]
+    while npml[0] + npml[1] >= Nx - 9:
+        npml[0], npml[1] = npml[0] // 2, npml[1] // 2
+    while npml[2] + npml[3] >= Nz - 1:
+        npml[2], npml[3] = npml[2] // 2, npml[3] // 2
+    prec = int(rng.choice([32, 64]))
+    K = po.consts()
+    dx, dz = 5e-8, 6e-8
+    dt = dx / (2 * K["c0"])
+    steps = 40
+    iJ, kJ = int(rng.integers(0, Nx)), int(rng.integers(0, Nz + 1))
+    import os
+    os.environ["FDTD_Z_CHUNK2D"] = str(int(rng.choice([1, 2, 5, 32])))
+    try:
+        eng = fdtd_amd.Engine2D(Nx, Nz, npml, dx, dz, dt, K["mu0"], K["eps0"], iJ, kJ, steps, precision=prec)
+    finally:
+        del os.environ["FDTD_Z_CHUNK2D"]
+    tw = po.Twin2D(prec, Nx, Nz, npml, dx, dz, dt, K["mu0"], K["eps0"], iJ, kJ, steps)
+    mask = np.zeros((Nx, Nz), dtype=bool)
+    if rng.random() < 0.5:
+        a = int(rng.integers(0, Nx)); mask[a:a + int(rng.integers(1, 40)), :] = True
+    else:
+        a = int(rng.integers(0, Nz)); mask[:, a:a + int(rng.integers(1, 6))] = True
+    if seed % 4 == 3:
+        mask[:] = False                                            # no dispersive cell at all
+    Cs = [np.where(mask, 0.02 * rng.random((Nx, Nz)), 0.0), np.where(mask, -1.9 + 0.01 * rng.random((Nx, Nz)), 0.0),
+          np.where(mask, 1 + 0.01 * rng.random((Nx, Nz)), 0.0)]
+    jy = rng.standard_normal(steps) * 1e3
+    dd = (dx, dz)
+    for be in (eng, tw):
+        for a in range(2):
+            for s in range(2):
+                if npml[a * 2 + s]:
+                    tabs = po.cpml_face(npml[a * 2 + s], s, dd[a], dz, dt)
+                    for k in range(6):
+                        be.set(po.D2_TAB + (a * 2 + s) * 6 + k, tabs[k])
+        for q in range(3):
+            be.set(po.D2_C1 + q, Cs[q])
+        be.set(po.D2_JY, jy)
+    eng.step(0, steps)
+    tw.step(0, steps)
+    for id_ in po.FIELDS2D + po.ALL_PHI2D:
+        if eng.size(id_):
+            util.assert_equal_arrays(eng.get(id_), tw.get(id_), f"seed {seed}: 2-D {Nx}x{Nz} npml={npml} fp{prec} source=({iJ},{kJ}), array {id_}")
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("seed", range(8))
+def test_random_configurations_half_step_kernels_equal_twin(seed, mode):
+    """The two-kernel paths on the same kind of random problems the fused kernel is checked on."""
+    from tests.test_gpu_fused import _random_case
+    rng = np.random.default_rng(300 + seed)
+    N, npml, prec, has_mu, rows, chunk = _random_case(rng)
+    K = po.consts()
+    d = (5e-8, 6e-8, 7e-8)
+    dt = 5e-8 / (2 * K["c0"])
+    steps = 13
+    kJ = int(rng.integers(0, N[2] + 1))
+    eng = fdtd_amd.Engine3D(N, npml, d, dt, K["mu0"], kJ, steps, precision=prec, mode=mode, has_mu=has_mu)
+    eng.tune(chunk, int(rng.integers(0, 2)), 1 + rows % 4)
+    tw = po.Twin3D(prec, N, npml, d, dt, K["mu0"], kJ, steps, has_mu)
+    wf = rng.standard_normal(steps)
+    mag = rng.random((N[0], N[1] + 1))
+    for be in (eng, tw):
+        for a in range(3):
+            for s in range(2):
+                if npml[a * 2 + s]:
+                    tabs = po.cpml_face(npml[a * 2 + s], s, d[a], d[a], dt)
+                    for k in range(6):
+                        be.set(po.tab_id(a, s, k), tabs[k])
+        be.set(po.JX_WF, wf)
+        be.set(po.JX_MAG, mag)
+        be.fill_materials(seed, K["eps0"], 4 * K["eps0"], K["mu0"], 3 * K["mu0"])
+    eng.step(0, steps)
+    tw.step(0, steps)
+    for id_ in po.FIELDS3D + po.ALL_PHI3D:
+        if eng.size(id_):
+            util.assert_equal_arrays(eng.get(id_), tw.get(id_), f"seed {seed} mode {mode}: N={N} npml={npml} fp{prec} mu={has_mu}, array {id_}")
