@@ -42,3 +42,17 @@ def test_two_and_three_ranks_equal_one(mode):
         assert many["checks"]["checksum_dx"] == one["checks"]["checksum_dx"]
         for key in ("metric", "value", "unit", "ms_per_step", "roofline", "scaling", "dtype", "config"):
             assert key in many
+
+
+def test_rccl_self_exchange_on_engine_memory():
+    """What one GPU can show of the RCCL path itself: the backend takes the tensors that alias the
+    engine's ghost planes, and batch_isend_irecv orders correctly against the kernels on the compute
+    stream (one rank exchanging with itself, see tests/helpers/nccl_self_exchange.py)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "nccl_self_exchange.py")], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.strip().splitlines()[-1] == "OK"
