@@ -144,3 +144,37 @@ def test_fused_slabs_equal_whole_grid_384():
                 cur[r + 1][E.HALO_RECV_LO][c].copy_(cur[r][E.HALO_SEND_UP][c])
     got = [sum(e.checksum(i) for e in engs) % 2 ** 64 for i in FIELDS]
     assert got == want
+
+
+def test_whole_memory_grid_equals_three_slabs():
+    """1024 x 1024 x 3072 cells on one GPU (242 GB with the fused kernel's two buffer sets; every array
+    holds 3.2e9 elements, beyond 32-bit indexing) against the same problem as three 1024-layer slabs, whose
+    arrays stay below 2^31 elements: identical checksums of D and B after 5 steps."""
+    N, steps = (1024, 1024, 3072), 5
+    whole = make(N, (20,) * 6, E.MODE_FUSED, True, steps=steps)
+    whole.step(0, steps)
+    want = [whole.checksum(i) for i in FIELDS]
+    e_whole = whole.sumsq(E.DX)
+    whole.close()
+    del whole
+    assert e_whole > 0 and np.isfinite(e_whole)
+    parts = slab.partition(N[2], 3)
+    engs = [make(N, (20,) * 6, E.MODE_FUSED, True, z_range=p, steps=steps) for p in parts]
+    pl = [[{w: [E.halo_tensor(e, w, c, par) for c in (0, 1)] for w in range(4)} for par in (0, 1)] for e in engs]
+    for n in range(steps):
+        for e in engs:
+            e.fused(n, E.PART_EDGE)
+        cur = [pl[r][engs[r].parity()] for r in range(3)]
+        for r in range(1, 3):
+            for c in (0, 1):
+                cur[r - 1][E.HALO_RECV_HI][c].copy_(cur[r][E.HALO_SEND_DOWN][c])
+        for e in engs:
+            e.fused(n, E.PART_TOP)
+        for e in engs:
+            e.fused_top()
+            e.fused(n, E.PART_INTERIOR)
+        for r in range(2):
+            for c in (0, 1):
+                cur[r + 1][E.HALO_RECV_LO][c].copy_(cur[r][E.HALO_SEND_UP][c])
+    got = [sum(e.checksum(i) for e in engs) % 2 ** 64 for i in FIELDS]
+    assert got == want
