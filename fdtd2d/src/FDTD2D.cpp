@@ -49,6 +49,7 @@ Sim2DConfig Sim2DConfig::reference_default() {
     c.k_Jy = c.Nz / 2;
     c.slab = 1;
     c.precision = 64;
+    c.fused = true;
     c.n_T0 = static_cast<int>(std::round(cfl * cells_per_wavelength));
     c.frame_every = 20;
     c.write_files = true;
@@ -64,6 +65,7 @@ void Sim2DConfig::apply_environment() {
     int v;
     if (env_int("FDTD2D_NPML", v)) for (int& n : n_pml) n = v;
     if (env_int("FDTD2D_WRITE", v)) write_files = v != 0;
+    if (env_int("FDTD2D_FUSED", v)) fused = v != 0;
     if (const char* e = std::getenv("FDTD2D_OUT")) if (*e) out_dir = e;
 }
 
@@ -88,6 +90,7 @@ void FDTD2D::build() {
     const bool source_on_grid = c.i_Jy >= 0 && c.i_Jy <= c.Nx && c.k_Jy >= 0 && c.k_Jy <= c.Nz;
     d.i_Jy = source_on_grid ? c.i_Jy : -1; d.k_Jy = source_on_grid ? c.k_Jy : -1;
     d.n_wf = c.steps; d.precision = c.precision; d.device = -1;
+    d.mode = c.fused ? FDTD2D_MODE_FUSED : FDTD2D_MODE_FULL;
     d.dx = c.dx; d.dz = c.dz; d.dt = c.dt; d.mu0 = mu0; d.eps0 = eps0;
     must(fdtd2d_create(&d, &m_engine), "fdtd2d_create");
 

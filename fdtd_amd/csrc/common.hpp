@@ -92,8 +92,8 @@ __host__ __device__ __forceinline__ double hash_unit(uint64_t seed, uint32_t str
 }
 
 // ---- probe time series: a handful of cells sampled after every step without leaving the device ----
-struct ProbeSpec { int num, den; long long off; };      // value = arr[num][off], divided by arr[den][off] (den >= 0) or by `scalar` (den == -2)
-template <typename T, int N> struct PtrTable { const T* p[N]; T scalar; };
+struct ProbeSpec { int num, den; long long off; double sdiv; };   // value = arr[num][off], divided by arr[den][off] (den >= 0) or by sdiv (den == -2)
+template <typename T, int N> struct PtrTable { const T* p[N]; };
 template <typename T, int N>
 __global__ void k_probe(PtrTable<T, N> t, const ProbeSpec* __restrict__ ps, int n_probes, T* __restrict__ row) {
     const int q = threadIdx.x;
@@ -101,7 +101,7 @@ __global__ void k_probe(PtrTable<T, N> t, const ProbeSpec* __restrict__ ps, int 
     const ProbeSpec s = ps[q];
     T v = t.p[s.num][s.off];
     if (s.den >= 0) v = v / t.p[s.den][s.off];
-    else if (s.den == -2) v = v / t.scalar;
+    else if (s.den == -2) v = v / (T)s.sdiv;
     row[q] = v;
 }
 constexpr int kMaxProbes = 64;

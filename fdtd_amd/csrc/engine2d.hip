@@ -1,5 +1,5 @@
 // engine2d.hip -- host side of the 2-D engine: device state, array exchange, launches, C ABI.
-#include "kernels2d.hpp"
+#include "kernels2d_fused.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -84,6 +84,16 @@ struct Engine2 : fdtd2d_engine {
     T* ph_x[2][2];      // [0 = ey, 1 = mz][side]   layout [k][strip]
     T* tab_d = nullptr; T* xrow_d = nullptr; double* red_d = nullptr;
     unsigned char* disp_d = nullptr;
+    // fused stepping: second Dy/Bx/Bz and D-side CPML buffers, a third Ey/SEy sample buffer, flags of
+    // the overlapping row segments, a scratch field for downloads of fields that only exist in registers
+    bool fused = false;
+    T* Dy2 = nullptr; T* Bx2 = nullptr; T* Bz2 = nullptr;
+    T* Ef = nullptr; T* SEf = nullptr;
+    T* ph_z2[2] = {nullptr, nullptr}; T* ph_x2[2] = {nullptr, nullptr};
+    unsigned char* disp2_d = nullptr;
+    T* tmp_field = nullptr;
+    T* xrow2_d = nullptr;
+    int ntx2 = 0, chunk_f = 4;        // rows per wave in the fused kernel (4 is the optimum at 8192^2; the closing row is computed twice)
     std::vector<double> tab_h;
     std::vector<T> Jy;
     int chunk = 1, remap = 1;      // rows per wave: at 8192^2 one row per wave is fastest (the row below comes from L2, and more waves are in flight)
@@ -103,7 +113,15 @@ struct Engine2 : fdtd2d_engine {
         int slot;
         if (id >= FDTD2D_C1) slot = 15 + (id - FDTD2D_C1);
         else { const int f = id / 7, r = id % 7; slot = r == 0 ? f : (r <= 2 ? 3 + f : (r == 3 ? 6 + f : (r <= 5 ? 9 + f : 12 + f))); }
-        return probes.add(ProbeSpec{slot, -1, off});
+        ProbeSpec sp{slot, -1, off, 1.0};
+        if (fused && id <= 20 && (id % 7 == 1 || id % 7 == 2)) {
+            // the current Ey / Hx / Hz of a cell without Lorentz coefficients only exists as Dy/eps0 (B/mu0)
+            const int f = id / 7;
+            T c[3];
+            for (int q = 0; q < 3; ++q) FDTD_HIP(hipMemcpy(&c[q], C[q] + off, sizeof(T), hipMemcpyDeviceToHost));
+            if (c[0] == (T)0 && c[1] == (T)0 && c[2] == (T)0 && k < d.Nz) { sp.num = f; sp.den = -2; sp.sdiv = f == 0 ? d.eps0 : d.mu0; }
+        }
+        return probes.add(sp);
     }
     int probe_record(hipStream_t s) override {
         if (probes.specs.empty()) return FDTD_OK;
@@ -112,7 +130,6 @@ struct Engine2 : fdtd2d_engine {
         PtrTable<T, 18> t;
         t.p[0] = Dy; t.p[1] = Bx; t.p[2] = Bz;
         for (int f = 0; f < 3; ++f) { t.p[3 + f] = Fa[f]; t.p[6 + f] = Fb[f]; t.p[9 + f] = Sa[f]; t.p[12 + f] = Sb[f]; t.p[15 + f] = C[f]; }
-        t.scalar = (T)1;
         hipLaunchKernelGGL((k_probe<T, 18>), dim3(1), dim3(kMaxProbes), 0, s, t, probes.specs_d, (int)probes.specs.size(), row);
         FDTD_HIP(hipGetLastError());
         return FDTD_OK;
@@ -156,15 +173,39 @@ struct Engine2 : fdtd2d_engine {
         if ((rc = dalloc((void**)&xrow_d, (size_t)6 * px * sizeof(T)))) return rc;
         if ((rc = dalloc((void**)&red_d, 1024 * sizeof(double)))) return rc;
         if ((rc = dalloc((void**)&disp_d, (size_t)nz1 * (px / (kLanes * V)) + 64))) return rc;
+        fused = d.mode == FDTD2D_MODE_FUSED;
+        if (fused) {
+            if (const char* e = getenv("FDTD_Z_CHUNK2D")) { int c = atoi(e); if (c >= 1 && c <= 65536) chunk_f = c; }
+            ntx2 = (d.Nx + (kLanes - 1) * V - 1) / ((kLanes - 1) * V);
+            if ((rc = dalloc((void**)&Dy2, fb)) || (rc = dalloc((void**)&Bx2, fb)) || (rc = dalloc((void**)&Bz2, fb)) ||
+                (rc = dalloc((void**)&Ef, fb)) || (rc = dalloc((void**)&SEf, fb)) || (rc = dalloc((void**)&tmp_field, fb))) return rc;
+            for (int s = 0; s < 2; ++s) {
+                if (np[1][s] && (rc = dalloc((void**)&ph_z2[s], ((size_t)np[1][s] * px + px) * sizeof(T)))) return rc;
+                if (np[0][s] && (rc = dalloc((void**)&ph_x2[s], ((size_t)nz1 * (s ? xwp : xwn) + px) * sizeof(T)))) return rc;
+            }
+            if ((rc = dalloc((void**)&disp2_d, (size_t)nz1 * ntx2 + 64))) return rc;
+            if ((rc = dalloc((void**)&xrow2_d, (size_t)6 * px * sizeof(T)))) return rc;
+            if ((rc = upload_tables())) return rc;
+        }
         Jy.assign(d.n_wf > 0 ? d.n_wf : 0, (T)0);
         return FDTD_OK;
     }
     size_t device_bytes() override { return bytes; }
+
+    // ---- fused mode: fields that only exist in registers during a step, formed on request
+    // family 0 = Ey (from Dy/eps0), 1 = Hx (Bx/mu0), 2 = Hz (Bz/mu0); rows the step never touches keep the stored sample
+    const T* current_field(int f, hipStream_t s) {
+        if (!fused) return Fa[f];
+        const T* raw = f == 0 ? Dy : (f == 1 ? Bx : Bz);
+        hipLaunchKernelGGL(k2_materialize<T>, dim3(2048), dim3(256), 0, s, raw, (const T*)Fa[f], (const T*)C[0], (const T*)C[1], (const T*)C[2], tmp_field,
+                           (T)(f == 0 ? d.eps0 : d.mu0), px, nz1, d.Nz);
+        return tmp_field;
+    }
     T* obs_acc = nullptr;
     int observe_accumulate(double weight, int reset, hipStream_t s) override {
         int rc;
         if (!obs_acc && (rc = dalloc((void**)&obs_acc, fsize * sizeof(T)))) return rc;
-        hipLaunchKernelGGL(k2_observe<T>, dim3(2048), dim3(256), 0, s, Fa[0], obs_acc, d.Nx, d.Nz, px, (T)weight, reset);
+        hipLaunchKernelGGL(k2_observe<T>, dim3(2048), dim3(256), 0, s, current_field(0, s), obs_acc, d.Nx, d.Nz, px, (T)weight, reset);
         FDTD_HIP(hipGetLastError());
         return FDTD_OK;
     }
@@ -178,14 +219,15 @@ struct Engine2 : fdtd2d_engine {
         return FDTD_OK;
     }
 
-    struct Map { int n0 = 0, n1 = 0; T* dev = nullptr; size_t dev_elems = 0; int kind = -1, s = 0; bool mag = false; };
+    struct Map { int n0 = 0, n1 = 0; T* dev = nullptr; T* dev2 = nullptr; size_t dev_elems = 0; int kind = -1, s = 0; bool mag = false; int fam = -1, slot = -1; };
     bool make_map(int id, Map& m) {
         if (id >= 0 && id <= 20) {
             const int f = id / 7, r = id % 7;
             m.n0 = d.Nx + (f != 2); m.n1 = d.Nz + (f != 1);
             m.kind = 0; m.dev_elems = fsize;
-            if (r == 0) m.dev = f == 0 ? Dy : (f == 1 ? Bx : Bz);
-            else if (r == 1 || r == 2) m.dev = Fa[f];
+            m.fam = f; m.slot = r;
+            if (r == 0) { m.dev = f == 0 ? Dy : (f == 1 ? Bx : Bz); m.dev2 = f == 0 ? Dy2 : (f == 1 ? Bx2 : Bz2); }
+            else if (r == 1 || r == 2) { m.dev = Fa[f]; if (f == 0) m.dev2 = Ef; }
             else if (r == 3) m.dev = Fb[f];
             else if (r == 4 || r == 5) m.dev = Sa[f];
             else m.dev = Sb[f];
@@ -195,8 +237,8 @@ struct Engine2 : fdtd2d_engine {
         if (id >= FDTD2D_PHI && id < FDTD2D_PHI + 8) {
             const int w = (id - FDTD2D_PHI) / 2; m.s = (id - FDTD2D_PHI) % 2;
             m.mag = w >= 2;
-            if (w == 0 || w == 2) { m.kind = 1; m.n0 = d.Nx + 1; m.n1 = np[1][m.s]; m.dev = ph_z[w / 2][m.s]; m.dev_elems = (size_t)np[1][m.s] * px; }
-            else { m.kind = 2; m.n0 = np[0][m.s]; m.n1 = d.Nz + 1; m.dev = ph_x[w / 2][m.s]; m.dev_elems = (size_t)nz1 * (m.s ? xwp : xwn); }
+            if (w == 0 || w == 2) { m.kind = 1; m.n0 = d.Nx + 1; m.n1 = np[1][m.s]; m.dev = ph_z[w / 2][m.s]; m.dev_elems = (size_t)np[1][m.s] * px; if (w == 0) m.dev2 = ph_z2[m.s]; }
+            else { m.kind = 2; m.n0 = np[0][m.s]; m.n1 = d.Nz + 1; m.dev = ph_x[w / 2][m.s]; m.dev_elems = (size_t)nz1 * (m.s ? xwp : xwn); if (w == 1) m.dev2 = ph_x2[m.s]; }
             return true;
         }
         return false;
@@ -234,6 +276,17 @@ struct Engine2 : fdtd2d_engine {
             if (z == Z_NEG || z == Z_POS) for (int q = 3; q < 6; ++q) xr[(size_t)q * px + i] = tb(z == Z_POS, q, l);
         }
         FDTD_HIP(hipMemcpy(xrow_d, xr.data(), xr.size() * sizeof(T), hipMemcpyHostToDevice));
+        if (fused) {
+            // the fused kernel's x terms are branch-free: plain columns carry (0, 0, dt/dx), columns the
+            // reference's sweeps skip (0, 0, 0)
+            const T cmid = (T)(d.dt / d.dx);
+            for (int i = 0; i < d.Nx; ++i) {
+                int l;
+                if (zone_e(i, d.Nx, np[0][0], np[0][1], l) == Z_MID) xr[(size_t)2 * px + i] = cmid;
+                if (zone_h(i, d.Nx, np[0][0], np[0][1], false, l) == Z_MID) xr[(size_t)5 * px + i] = cmid;
+            }
+            FDTD_HIP(hipMemcpy(xrow2_d, xr.data(), xr.size() * sizeof(T), hipMemcpyHostToDevice));
+        }
         return FDTD_OK;
     }
     int set_array(int id, const double* host, size_t n) override {
@@ -254,6 +307,12 @@ struct Engine2 : fdtd2d_engine {
             if (off >= 0) st[(size_t)off] = (T)host[o];
         }
         FDTD_HIP(hipMemcpy(m.dev, st.data(), st.size() * sizeof(T), hipMemcpyHostToDevice));
+        if (m.dev2) FDTD_HIP(hipMemcpy(m.dev2, st.data(), st.size() * sizeof(T), hipMemcpyHostToDevice));
+        if (fused && id >= FDTD2D_C1 && id <= FDTD2D_C3) {
+            const size_t tiles = (size_t)nz1 * ntx2;
+            hipLaunchKernelGGL((k2_flags_fused<T, V>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, 0, C[0], C[1], C[2], disp2_d, px, nz1, ntx2);
+            FDTD_HIP(hipGetLastError());
+        }
         if (id >= FDTD2D_C1 && id <= FDTD2D_C3) {
             const int ntx = px / (kLanes * V);
             const size_t tiles = (size_t)nz1 * ntx;
@@ -270,9 +329,11 @@ struct Engine2 : fdtd2d_engine {
         Map m;
         if (!make_map(id, m)) return fail(FDTD_ERR_ARG, "get_array: unknown array id %d", id);
         if (n == 0) return FDTD_OK;
+        const T* src = m.dev;
+        if (fused && m.fam >= 0 && (m.slot == 1 || m.slot == 2)) { src = current_field(m.fam, 0); FDTD_HIP(hipGetLastError()); }
         FDTD_HIP(hipDeviceSynchronize());
         std::vector<T> st(m.dev_elems);
-        FDTD_HIP(hipMemcpy(st.data(), m.dev, st.size() * sizeof(T), hipMemcpyDeviceToHost));
+        FDTD_HIP(hipMemcpy(st.data(), src, st.size() * sizeof(T), hipMemcpyDeviceToHost));
         size_t o = 0;
         for (int p0 = 0; p0 < m.n0; ++p0) for (int p1 = 0; p1 < m.n1; ++p1, ++o) {
             const long long off = dev_off(m, p0, p1);
@@ -283,7 +344,8 @@ struct Engine2 : fdtd2d_engine {
     int sumsq(int id, double* out, hipStream_t s) override {
         Map m;
         if (!make_map(id, m) || m.kind != 0) return fail(FDTD_ERR_ARG, "sumsq: array %d is not a field", id);
-        hipLaunchKernelGGL(k2_sumsq<T>, dim3(1024), dim3(256), 0, s, m.dev, d.Nx, px, nz1, red_d);
+        const T* src = (fused && m.fam >= 0 && (m.slot == 1 || m.slot == 2)) ? current_field(m.fam, s) : m.dev;
+        hipLaunchKernelGGL(k2_sumsq<T>, dim3(1024), dim3(256), 0, s, src, d.Nx, px, nz1, red_d);
         FDTD_HIP(hipGetLastError());
         std::vector<double> h(1024);
         FDTD_HIP(hipMemcpyAsync(h.data(), red_d, 1024 * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -313,7 +375,43 @@ struct Engine2 : fdtd2d_engine {
         a.nbz = (nz1 + chunk - 1) / chunk;
         return a;
     }
+    int step_fused(int n, hipStream_t s) {
+        K2F<T> a;
+        a.Dy = Dy; a.Bx = Bx; a.Bz = Bz; a.Dyn = Dy2; a.Bxn = Bx2; a.Bzn = Bz2;
+        a.Ec = Fa[0]; a.Ep = Fb[0]; a.En = Ef; a.SEc = Sa[0]; a.SEp = Sb[0]; a.SEn = SEf;
+        for (int f = 0; f < 2; ++f) { a.H1[f] = Fa[1 + f]; a.H2[f] = Fb[1 + f]; a.SH1[f] = Sa[1 + f]; a.SH2[f] = Sb[1 + f]; }
+        a.C1 = C[0]; a.C2 = C[1]; a.C3 = C[2];
+        for (int sd = 0; sd < 2; ++sd) {
+            a.pe_z[sd] = ph_z[0][sd]; a.pe_zn[sd] = ph_z2[sd]; a.pe_x[sd] = ph_x[0][sd]; a.pe_xn[sd] = ph_x2[sd];
+            a.pm_z[sd] = ph_z[1][sd]; a.pm_x[sd] = ph_x[1][sd];
+        }
+        a.tab = tab_d; a.xrow = xrow2_d; a.disp = disp2_d;
+        a.Nx = d.Nx; a.Nz = d.Nz; a.px = px; a.nz1 = nz1;
+        for (int ax = 0; ax < 2; ++ax) for (int sd = 0; sd < 2; ++sd) a.np[ax][sd] = np[ax][sd];
+        a.xwn = xwn; a.xwp = xwp; a.xp0 = xp0;
+        a.iJ = d.i_Jy; a.kJ = d.k_Jy;
+        a.src_on = (n >= 0 && n < (int)Jy.size()) ? 1 : 0;
+        a.dt = (T)d.dt; a.dtd[0] = (T)(d.dt / d.dx); a.dtd[1] = (T)(d.dt / d.dz); a.mu0 = (T)d.mu0; a.eps0 = (T)d.eps0;
+        a.jy = a.src_on ? a.dt * Jy[n] : (T)0;
+        a.chunk = chunk_f; a.remap = remap; a.ntx = ntx2;
+        a.nbx = (ntx2 + kWavesPerBlock - 1) / kWavesPerBlock;
+        a.nbz = (nz1 + chunk_f - 1) / chunk_f;
+        timer.begin(2, s);
+        hipLaunchKernelGGL(k2_fused<T>, dim3((unsigned)a.nbx * a.nbz), dim3(256), 0, s, a);
+        timer.end(s);
+        FDTD_HIP(hipGetLastError());
+        std::swap(Dy, Dy2); std::swap(Bx, Bx2); std::swap(Bz, Bz2);
+        for (int sd = 0; sd < 2; ++sd) { std::swap(ph_z[0][sd], ph_z2[sd]); std::swap(ph_x[0][sd], ph_x2[sd]); }
+        { T* t = Fb[0]; Fb[0] = Fa[0]; Fa[0] = Ef; Ef = t; }            // new -> n-1 -> n-2 -> free
+        { T* t = Sb[0]; Sb[0] = Sa[0]; Sa[0] = SEf; SEf = t; }
+        for (int f = 1; f < 3; ++f) { std::swap(Fa[f], Fb[f]); std::swap(Sa[f], Sb[f]); }
+        return probe_record(s);
+    }
     int step(int n0, int count, hipStream_t s) override {
+        if (fused) {
+            for (int n = n0; n < n0 + count; ++n) if (int rc = step_fused(n, s)) return rc;
+            return FDTD_OK;
+        }
         for (int n = n0; n < n0 + count; ++n) {
             K2<T> a = args();
             a.src_on = (n >= 0 && n < (int)Jy.size()) ? 1 : 0;
@@ -346,6 +444,7 @@ int fdtd2d_create(const fdtd2d_desc* d, fdtd2d_handle* out) {
     if (!d) return fail(FDTD_ERR_ARG, "null descriptor");
     if (d->struct_size != (int32_t)sizeof(fdtd2d_desc)) return fail(FDTD_ERR_ARG, "descriptor size %d, library expects %zu", d->struct_size, sizeof(fdtd2d_desc));
     if (d->precision != 32 && d->precision != 64) return fail(FDTD_ERR_ARG, "precision must be 32 or 64");
+    if (d->mode != FDTD2D_MODE_FULL && d->mode != FDTD2D_MODE_FUSED) return fail(FDTD_ERR_ARG, "unknown 2-D mode %d", d->mode);
     if (d->Nx < 2 || d->Nz < 2) return fail(FDTD_ERR_ARG, "grid too small");
     for (int q = 0; q < 4; ++q) if (d->n_pml[q] < 0 || d->n_pml[q] > kMaxLayers) return fail(FDTD_ERR_ARG, "CPML layer counts must be in [0,%d]", kMaxLayers);
     if (d->n_pml[0] + d->n_pml[1] >= d->Nx || d->n_pml[2] + d->n_pml[3] >= d->Nz) return fail(FDTD_ERR_ARG, "CPML layers do not fit the grid");

@@ -219,7 +219,7 @@ struct Engine3 : fdtd3d_engine {
         const long long off = dev_off(m, i, j, k, owned);
         if (off == -2) return fail(FDTD_ERR_ARG, "probe_add: column %d of array %d is the wall column, always zero", i, id);
         if (off < 0 || !owned) return fail(FDTD_ERR_ARG, "probe_add: layer %d is not owned by this slab [%d,%d)", k, d.z_lo, d.z_hi);
-        ProbeSpec sp{id, -1, off};
+        ProbeSpec sp{id, -1, off, d.mu0};
         const int fam = id / 3, c = id % 3;
         if (!full && fam == 1) { sp.num = c; sp.den = 12 + c; }
         if (!full && fam == 3) { sp.num = 6 + c; sp.den = d.has_mu ? 15 + c : -2; }
@@ -232,7 +232,6 @@ struct Engine3 : fdtd3d_engine {
         if (int rc = probes.next_row(&row, (int)wf.size() + 8)) return rc;
         PtrTable<T, 18> t;
         for (int q = 0; q < 18; ++q) t.p[q] = fld[q];
-        t.scalar = (T)d.mu0;
         hipLaunchKernelGGL((k_probe<T, 18>), dim3(1), dim3(kMaxProbes), 0, s, t, probes.specs_d, (int)probes.specs.size(), row);
         FDTD_HIP(hipGetLastError());
         return FDTD_OK;

@@ -23,6 +23,7 @@ DX, DY, DZ, EX, EY, EZ, BX, BY, BZ, HX, HY, HZ = range(12)
 EPS_X, EPS_Y, EPS_Z, MU_X, MU_Y, MU_Z = range(12, 18)
 PHI_E, PHI_M, TAB, JX_MAG, JX_WF = 100, 200, 300, 400, 401
 MODE_FULL, MODE_LEAN, MODE_FUSED = 0, 1, 2
+MODE2D_FULL, MODE2D_FUSED = 0, 1
 PART_ALL, PART_EDGE, PART_INTERIOR, PART_TOP = 0, 1, 2, 3
 HALO_SEND_UP, HALO_RECV_LO, HALO_SEND_DOWN, HALO_RECV_HI = 0, 1, 2, 3
 
@@ -49,7 +50,7 @@ class Desc2D(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("Nx", C.c_int32), ("Nz", C.c_int32), ("n_pml", C.c_int32 * 4),
                 ("i_Jy", C.c_int32), ("k_Jy", C.c_int32), ("n_wf", C.c_int32), ("precision", C.c_int32),
                 ("device", C.c_int32), ("dx", C.c_double), ("dz", C.c_double), ("dt", C.c_double),
-                ("mu0", C.c_double), ("eps0", C.c_double)]
+                ("mu0", C.c_double), ("eps0", C.c_double), ("mode", C.c_int32), ("reserved", C.c_int32)]
 
 
 _lib = None
@@ -256,10 +257,10 @@ class Engine2D(_Common):
     """Device-resident 2-D (Ey, Hx, Hz) state with Lorentz histories plus its two kernels."""
     _p = "fdtd2d_"
 
-    def __init__(self, Nx, Nz, npml, dx, dz, dt, mu0, eps0, i_Jy, k_Jy, n_wf, precision=32, device=-1):
+    def __init__(self, Nx, Nz, npml, dx, dz, dt, mu0, eps0, i_Jy, k_Jy, n_wf, precision=32, device=-1, mode=0):
         self.Nx, self.Nz, self.npml, self.precision = Nx, Nz, tuple(npml), precision
         desc = Desc2D(C.sizeof(Desc2D), Nx, Nz, (C.c_int32 * 4)(*npml), i_Jy, k_Jy, n_wf, precision, device,
-                      dx, dz, dt, mu0, eps0)
+                      dx, dz, dt, mu0, eps0, mode, 0)
         self.desc = desc
         self.h = C.c_void_p()
         _check(lib().fdtd2d_create(C.byref(desc), C.byref(self.h)), "fdtd2d_create")

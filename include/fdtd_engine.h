@@ -249,7 +249,18 @@ typedef struct fdtd2d_desc {
     int32_t device;
     double dx, dz, dt;
     double mu0, eps0;         /* FDTD2D.h:19-20 */
+    int32_t mode;             /* FDTD2D_MODE_* */
+    int32_t reserved;
 } fdtd2d_desc;
+
+/* 2-D storage / stepping modes.  FULL: every array of the reference resident, two kernels per step.
+ * FUSED: one kernel per step; Ey, Hx, Hz (and their histories and polarisation sums) are only kept in
+ * memory at cells with a non-zero Lorentz coefficient -- elsewhere the field is Dy/eps0 (B/mu0), formed
+ * on the fly, and downloads of the current Ey, Hx, Hz derive it the same way; history samples and
+ * polarisation sums downloaded from such cells are meaningless (the recursion never reads them there).
+ * Upload the coefficient arrays before stepping. */
+#define FDTD2D_MODE_FULL 0
+#define FDTD2D_MODE_FUSED 1
 
 typedef struct fdtd2d_engine* fdtd2d_handle;
 

@@ -1,0 +1,142 @@
+"""The one-kernel 2-D step (FDTD2D_MODE_FUSED) against the golden vectors and the twin (needs a GPU).
+
+In this mode Ey, Hx, Hz only live in memory at cells with a non-zero Lorentz coefficient; downloads of
+the current fields derive the rest from Dy/eps0 and B/mu0.  History samples and polarisation sums are
+therefore compared at the dispersive cells only -- the recursion never reads them anywhere else."""
+import os
+
+import numpy as np
+import pytest
+
+import fdtd_amd
+from fdtd_amd.engine import MODE2D_FUSED
+from oracle import pyoracle as po
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+CURRENT = (po.D2_DY, po.D2_EY, po.D2_BX, po.D2_HX, po.D2_BZ, po.D2_HZ)
+
+
+def compare_2d(eng, ref_get, Nx, Nz, npml, mask, what):
+    """mask: [Nx][Nz] bool, cells with a non-zero coefficient."""
+    for id_ in po.FIELDS2D + po.ALL_PHI2D:
+        if not eng.size(id_):
+            continue
+        shp = po.shape2d(id_, Nx, Nz, npml)
+        got, want = eng.get(id_, shp), np.asarray(ref_get(id_)).reshape(shp)
+        if id_ in CURRENT or id_ >= 100 or id_ % 7 == 2:          # current fields (n1 is the current sample), CPML state
+            util.assert_equal_arrays(got, want, f"{what} array {id_}")
+        else:                                                      # older samples and polarisation sums: dispersive cells only
+            g, w = got[:Nx, :Nz][mask], want[:Nx, :Nz][mask]
+            util.assert_equal_arrays(g, w, f"{what} array {id_} at dispersive cells")
+
+
+@pytest.mark.parametrize("prec", [32, 64])
+@pytest.mark.parametrize("chunk", [1, 7, 64])
+def test_fused2d_lorentz_slab(prec, chunk):
+    """The reference's default slab problem (golden g4): fp64 == compiled reference, fp32 == fp32 twin."""
+    meta, ins, outs, _ = util.load_fixture("g4_2d_slab")
+    os.environ["FDTD_Z_CHUNK2D"] = str(chunk)
+    try:
+        eng = fdtd_amd.Engine2D(meta["Nx"], meta["Nz"], meta["npml"], meta["dx"], meta["dz"], meta["dt"], meta["mu0"], meta["eps0"],
+                                meta["i_Jy"], meta["k_Jy"], meta["steps"], precision=prec, mode=MODE2D_FUSED)
+    finally:
+        del os.environ["FDTD_Z_CHUNK2D"]
+    util.feed(eng, ins)
+    eng.step(0, meta["steps"])
+    mask = np.asarray(ins[po.D2_C1]).reshape(meta["Nx"], meta["Nz"]) != 0
+    assert mask.any() and not mask.all()
+    if prec == 64:
+        ref_get = lambda id_: outs[(meta["steps"], id_)]
+    else:
+        tw = util.twin2d_from_meta(meta, 32)
+        util.feed(tw, ins)
+        tw.step(0, meta["steps"])
+        ref_get = tw.get
+    compare_2d(eng, ref_get, meta["Nx"], meta["Nz"], meta["npml"], mask, f"g4 fused fp{prec} chunk {chunk}")
+
+
+def test_fused2d_pec512_point_source():
+    """512 x 512, PEC walls, no dispersive cell, 2000 steps: snapshots, sums and the probe series == reference (fp64)."""
+    meta, ins, outs, extra = util.load_fixture("g5_2d_pec512")
+    eng = fdtd_amd.Engine2D(meta["Nx"], meta["Nz"], meta["npml"], meta["dx"], meta["dz"], meta["dt"], meta["mu0"], meta["eps0"],
+                            meta["i_Jy"], meta["k_Jy"], meta["steps"], precision=64, mode=MODE2D_FUSED)
+    util.feed(eng, ins)
+    eng.probe_add(po.D2_EY, *meta["probe_cell"])
+    shp = po.shape2d(po.D2_EY, meta["Nx"], meta["Nz"], meta["npml"])
+    sub = meta["subsample"]
+    n = 0
+    for snap in meta["snapshots"]:
+        eng.step(n, snap - n)
+        n = snap
+        ey = eng.get(po.D2_EY, shp)
+        util.assert_equal_arrays(ey[::sub, ::sub], outs[(snap, po.D2_EY)], f"g5 fused Ey at {snap}")
+        assert util.seq_sumsq(ey) == meta["sumsq_ey"][str(snap)]
+        assert abs(eng.sumsq(po.D2_EY) / meta["sumsq_ey"][str(snap)] - 1) < 1e-12
+    util.assert_equal_arrays(eng.probe_read()[:, 0], extra["probe"], "g5 fused probe series")
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fused2d_random_configurations_equal_twin(seed):
+    rng = np.random.default_rng(900 + seed)
+    Nx = int(rng.choice([rng.integers(8, 60), rng.integers(245, 262), rng.integers(500, 700)]))
+    Nz = int(rng.integers(6, 50))
+    npml = [int(rng.integers(0, 6)) if rng.random() < 0.7 else 0 for _ in range(4)]
+    while npml[0] + npml[1] >= Nx - 9:
+        npml[0], npml[1] = npml[0] // 2, npml[1] // 2
+    while npml[2] + npml[3] >= Nz - 1:
+        npml[2], npml[3] = npml[2] // 2, npml[3] // 2
+    prec = int(rng.choice([32, 64]))
+    K = po.consts()
+    dx, dz = 5e-8, 6e-8
+    dt = dx / (2 * K["c0"])
+    steps = 41
+    iJ, kJ = int(rng.integers(0, Nx)), int(rng.integers(0, Nz + 1))
+    os.environ["FDTD_Z_CHUNK2D"] = str(int(rng.choice([1, 2, 5, 16, 100])))
+    try:
+        eng = fdtd_amd.Engine2D(Nx, Nz, npml, dx, dz, dt, K["mu0"], K["eps0"], iJ, kJ, steps, precision=prec, mode=MODE2D_FUSED)
+    finally:
+        del os.environ["FDTD_Z_CHUNK2D"]
+    tw = po.Twin2D(prec, Nx, Nz, npml, dx, dz, dt, K["mu0"], K["eps0"], iJ, kJ, steps)
+    mask = np.zeros((Nx, Nz), dtype=bool)
+    kind = seed % 4
+    if kind == 0:
+        a = int(rng.integers(0, Nx)); mask[a:a + int(rng.integers(1, 40)), :] = True
+    elif kind == 1:
+        a = int(rng.integers(0, Nz)); mask[:, a:a + int(rng.integers(1, 6))] = True
+    elif kind == 2:
+        mask[rng.random((Nx, Nz)) < 0.02] = True                   # isolated dispersive cells
+    Cs = [np.where(mask, 0.02 * rng.random((Nx, Nz)), 0.0), np.where(mask, -1.9 + 0.01 * rng.random((Nx, Nz)), 0.0),
+          np.where(mask, 1 + 0.01 * rng.random((Nx, Nz)), 0.0)]
+    mask = (Cs[0] != 0) | (Cs[1] != 0) | (Cs[2] != 0)
+    jy = rng.standard_normal(steps) * 1e3
+    dd = (dx, dz)
+    for be in (eng, tw):
+        for a in range(2):
+            for s in range(2):
+                if npml[a * 2 + s]:
+                    tabs = po.cpml_face(npml[a * 2 + s], s, dd[a], dz, dt)
+                    for k in range(6):
+                        be.set(po.D2_TAB + (a * 2 + s) * 6 + k, tabs[k])
+        for q in range(3):
+            be.set(po.D2_C1 + q, Cs[q])
+        be.set(po.D2_JY, jy)
+    eng.step(0, steps)
+    tw.step(0, steps)
+    compare_2d(eng, tw.get, Nx, Nz, npml, mask, f"seed {seed}: 2-D fused {Nx}x{Nz} npml={npml} fp{prec} source=({iJ},{kJ})")
+
+
+def test_fused2d_observables_equal_twin():
+    meta, ins, _, _ = util.load_fixture("g4_2d_slab")
+    eng = fdtd_amd.Engine2D(meta["Nx"], meta["Nz"], meta["npml"], meta["dx"], meta["dz"], meta["dt"], meta["mu0"], meta["eps0"],
+                            meta["i_Jy"], meta["k_Jy"], meta["steps"], precision=32, mode=MODE2D_FUSED)
+    tw = util.twin2d_from_meta(meta, 32)
+    util.feed(eng, ins)
+    util.feed(tw, ins)
+    for n in range(30):
+        eng.step(n, 1)
+        tw.step(n, 1)
+        eng.observe_accumulate(0.05, n % 10 == 0)
+        tw.observe_accumulate(0.05, n % 10 == 0)
+    util.assert_equal_arrays(eng.observe_rms(), tw.observe_rms(), "2-D fused RMS window")

@@ -94,6 +94,10 @@ def test_fdtd2d_driver_writes_the_reference_files(tmp_path):
                               FDTD2D_IJY=meta["i_Jy"], FDTD2D_KJY=meta["k_Jy"], FDTD2D_PRECISION=64), str(tmp_path))
     assert "Done. CSV in ./output_2d" in out
     names = _compare_dir(str(tmp_path / "output_2d"), fx)
+    # the two-kernel path writes the same files
+    _run("fdtd2d", dict(FDTD2D_NX=meta["Nx"], FDTD2D_NZ=meta["Nz"], FDTD2D_NPML=meta["npml"][0], FDTD2D_STEPS=meta["steps"],
+                        FDTD2D_IJY=meta["i_Jy"], FDTD2D_KJY=meta["k_Jy"], FDTD2D_PRECISION=64, FDTD2D_FUSED=0), str(tmp_path))
+    _compare_dir(str(tmp_path / "output_2d"), fx)
     assert "dims.txt" in names and "eymag_t00080.csv" in names and "ey_t00081.csv" in names
 
 
