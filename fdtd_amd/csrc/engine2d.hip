@@ -93,7 +93,7 @@ struct Engine2 : fdtd2d_engine {
     unsigned char* disp2_d = nullptr;
     T* tmp_field = nullptr;
     T* xrow2_d = nullptr;
-    int ntx2 = 0, chunk_f = 4;        // rows per wave in the fused kernel (4 is the optimum at 8192^2; the closing row is computed twice)
+    int ntx2 = 0, chunk_f = 2;        // rows per wave in the fused kernel (2 is the optimum at 8192^2 with four stacked waves per workgroup)
     std::vector<double> tab_h;
     std::vector<T> Jy;
     int chunk = 1, remap = 1;      // rows per wave: at 8192^2 one row per wave is fastest (the row below comes from L2, and more waves are in flight)
@@ -394,10 +394,10 @@ struct Engine2 : fdtd2d_engine {
         a.dt = (T)d.dt; a.dtd[0] = (T)(d.dt / d.dx); a.dtd[1] = (T)(d.dt / d.dz); a.mu0 = (T)d.mu0; a.eps0 = (T)d.eps0;
         a.jy = a.src_on ? a.dt * Jy[n] : (T)0;
         a.chunk = chunk_f; a.remap = remap; a.ntx = ntx2;
-        a.nbx = (ntx2 + kWavesPerBlock - 1) / kWavesPerBlock;
-        a.nbz = (nz1 + chunk_f - 1) / chunk_f;
+        a.nbx = ntx2;                                              // a workgroup = four consecutive row chunks of one x tile
+        a.nbz = (nz1 + kStack2D * chunk_f - 1) / (kStack2D * chunk_f);
         timer.begin(2, s);
-        hipLaunchKernelGGL(k2_fused<T>, dim3((unsigned)a.nbx * a.nbz), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k2_fused<T>, dim3((unsigned)a.nbx * a.nbz), dim3(kLanes * kStack2D), 0, s, a);
         timer.end(s);
         FDTD_HIP(hipGetLastError());
         std::swap(Dy, Dy2); std::swap(Bx, Bx2); std::swap(Bz, Bz2);

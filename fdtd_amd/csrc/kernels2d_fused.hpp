@@ -71,8 +71,10 @@ __device__ __forceinline__ T field_of1(T raw, T scale, bool flagged, const T* st
 // once per row instead of being kept in registers.  Columns past the grid hold zeros in every input,
 // which keeps them zero without per-element masks; `first` leaves the wall column i = 0 alone where the
 // reference's sweeps start at 1.
+constexpr int kStack2D = 4;      // waves (= consecutive row chunks) per workgroup of the fused 2-D kernel
+
 template <typename T>
-__global__ void __launch_bounds__(256) k2_fused(const K2F<T> a) {
+__global__ void __launch_bounds__(kLanes * kStack2D) k2_fused(const K2F<T> a) {
     constexpr int V = VecWidth<T>::V;
     constexpr int OWN = (kLanes - 1) * V;                // columns a wave owns; it computes D and E for one pack more
     using P = Pack<T, V>;
@@ -81,8 +83,11 @@ __global__ void __launch_bounds__(256) k2_fused(const K2F<T> a) {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned bid = a.remap ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
     const int bx = bid % a.nbx, bz = bid / a.nbx;
-    const int tx = bx * kWavesPerBlock + w;
-    if (tx >= a.ntx) return;                             // waves are independent: no barrier anywhere below
+    // the waves of a workgroup sit on consecutive row chunks of one x tile: the row that closes a wave's
+    // chunk is the first row of the wave above, which hands its Ey_new over through LDS (one barrier per
+    // kernel); only the top wave of a group computes its closing row itself
+    __shared__ T handover[kStack2D][kLanes * V];
+    const int tx = bx;
     const int c0 = tx * OWN, i0 = c0 + lane * V;
     const int px = a.px, Nz = a.Nz;
     const bool valid = i0 < px;                          // the overlap pack of the last tile may lie past the row
@@ -94,8 +99,10 @@ __global__ void __launch_bounds__(256) k2_fused(const K2F<T> a) {
     P xCe = ldg<T, V>(a.xrow + 2 * (size_t)px + c0, lo), xCm = ldg<T, V>(a.xrow + 5 * (size_t)px + c0, lo);
     if (!valid) { xCe = zero_pack<T, V>(); xCm = xCe; }
     const T* face_z = a.tab + (size_t)(1 * 2) * 6 * kMaxLayers;
-    const int kb = bz * a.chunk, ke = min(kb + a.chunk, a.nz1);
-    const int k_end = ke < a.nz1 ? ke + 1 : ke;          // one more D/E iteration closes the chunk
+    const int kb = (bz * kStack2D + w) * a.chunk, ke = min(kb + a.chunk, a.nz1);
+    if (kb >= a.nz1) { __syncthreads(); return; }        // no rows left for this wave: it only joins the group's barrier
+    const int k_end = ke < a.nz1 ? ke + 1 : ke;          // one more iteration closes the chunk
+    const bool from_above = ke < a.nz1 && w + 1 < kStack2D;   // the closing row's Ey_new comes from the wave above
     const bool src_lane = valid && a.iJ >= i0 && a.iJ < i0 + V;
 
     size_t ro = (size_t)kb * px + c0;                    // uniform offset of the wave's row segment
@@ -118,9 +125,13 @@ __global__ void __launch_bounds__(256) k2_fused(const K2F<T> a) {
         const bool row_in = k >= 1 && k < Nz, row_lt = k < Nz;
 
         // ---------------------------------------------------------------- row k: H_old, Dy_new, Ey_new
-        P d = ldg<T, V>(ap->Dy + ro, lo), bxo = ldg<T, V>(ap->Bx + ro, lo), bzo = ldg<T, V>(ap->Bz + ro, lo);
+        P ey = zero_pack<T, V>(), hx = ey, bxo = ey, bzo = ey;
+        if (k == ke && from_above) {
+            ey = ldv<T, V>(&handover[w + 1][lane * V]);
+        } else {
+        P d = ldg<T, V>(ap->Dy + ro, lo); bxo = ldg<T, V>(ap->Bx + ro, lo), bzo = ldg<T, V>(ap->Bz + ro, lo);
         if (!valid) { d = zero_pack<T, V>(); bxo = d; bzo = d; }
-        P hx = field_of<T, V>(bxo, a.mu0, flag, ap->H1[0] + ro, ap->C1 + ro, ap->C2 + ro, ap->C3 + ro, lo);
+        hx = field_of<T, V>(bxo, a.mu0, flag, ap->H1[0] + ro, ap->C1 + ro, ap->C2 + ro, ap->C3 + ro, lo);
         P hz = field_of<T, V>(bzo, a.mu0, flag, ap->H1[1] + ro, ap->C1 + ro, ap->C2 + ro, ap->C3 + ro, lo);
         if (!valid) { hx = zero_pack<T, V>(); hz = hx; }
         T hz_l = __shfl_up(hz.v[V - 1], 1);
@@ -143,7 +154,6 @@ __global__ void __launch_bounds__(256) k2_fused(const K2F<T> a) {
             for (int e = 0; e < V; ++e) if (i0 + e == a.iJ) d.v[e] = d.v[e] - a.jy;
         }
         if (st) stg_nt<T, V>(ap->Dyn + ro, lo, d);
-        P ey = zero_pack<T, V>();
         if (row_lt) {
             if (flag) {
                 const P c1 = ldg<T, V>(ap->C1 + ro, lo), c2 = ldg<T, V>(ap->C2 + ro, lo), c3 = ldg<T, V>(ap->C3 + ro, lo);
@@ -156,6 +166,11 @@ __global__ void __launch_bounds__(256) k2_fused(const K2F<T> a) {
                 ey = divide<T, V>(d, a.eps0);
             }
             if (!valid) ey = zero_pack<T, V>();
+        }
+        }
+        if (k == kb) {                                    // every wave with rows passes here exactly once
+            stv<T, V>(&handover[w][lane * V], ey);
+            __syncthreads();
         }
 
         // ---------------------------------------------------------------- row k-1: B_new, H_new
