@@ -178,3 +178,28 @@ def test_whole_memory_grid_equals_three_slabs():
                 cur[r + 1][E.HALO_RECV_LO][c].copy_(cur[r][E.HALO_SEND_UP][c])
     got = [sum(e.checksum(i) for e in engs) % 2 ** 64 for i in FIELDS]
     assert got == want
+
+
+def test_2d_8192_fused_equals_two_kernel_path():
+    """8192 x 8192 with 20-layer CPML and the reference's Lorentz slab (the 2-D benchmark workload):
+    the one-kernel step and the two-kernel step leave identical Ey, Dy, Bx, Bz (sums in the same
+    reduction order) and identical probe series at cells inside, beside and far from the slab."""
+    N, steps = 8192, 150
+    K = fs.constants()
+    dx = K["c0"] / 1.5e14 / 40
+    dt = dx / (2 * K["c0"])
+    results = []
+    for mode in (E.MODE2D_FULL, E.MODE2D_FUSED):
+        eng = fdtd_amd.Engine2D(N, N, (20,) * 4, dx, dx, dt, K["mu0"], K["eps0"], N // 2 - 40, N // 2, steps, precision=32, mode=mode)
+        fs.load_cpml2d(eng, dx, dx, dt)
+        eng.set(E.D2_JY, fs.default_source2d(steps, dx, dx, dt))
+        for q, c in enumerate(fs.default_lorentz2d(N, N, dt)):
+            eng.set(E.D2_C1 + q, c)
+        for cell in ((N // 2, N // 2), (N // 2 - 25, N // 2 + 3), (N // 2 - 60, N // 2 - 40), (10, 4000)):
+            eng.probe_add(E.D2_EY, *cell)
+        eng.probe_add(E.D2_HZ, N // 2 + 5, N // 2 + 1)
+        eng.step(0, steps)
+        results.append(([eng.sumsq(i) for i in (E.D2_DY, E.D2_EY, E.D2_BX, E.D2_HX, E.D2_BZ, E.D2_HZ)], eng.probe_read()))
+        eng.close()
+    assert results[0][0] == results[1][0] and results[0][0][1] > 0
+    assert np.array_equal(results[0][1], results[1][1]) and np.abs(results[0][1]).max() > 0
