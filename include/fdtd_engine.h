@@ -283,6 +283,7 @@ int fdtd2d_probe_add(fdtd2d_handle h, int id, int i, int k);
 int fdtd2d_probe_record(fdtd2d_handle h, void* stream);
 int fdtd2d_probe_read(fdtd2d_handle h, double* out, size_t cap, int* n_samples, int* n_probes);
 int fdtd2d_probe_reset(fdtd2d_handle h, int drop_probes);
+/* Kernel timing as in 3-D; kinds: 0 = E part, 1 = H part, 2 = fused step. */
 int fdtd2d_kernel_timing(fdtd2d_handle h, int enable);
 int fdtd2d_kernel_time(fdtd2d_handle h, int kind, int* launches, double* total_ms);
 
