@@ -6,6 +6,8 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -23,6 +25,40 @@ int fail(int code, const char* fmt, ...);
         if (e_ != hipSuccess)                                                                  \
             return ::fdtd::fail(FDTD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+
+// Makes `want` the calling thread's current device for the lifetime of the object and puts the
+// caller's device back afterwards, so engines on several devices can share one host thread.
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    hipError_t status = hipSuccess;
+    explicit DeviceScope(int want) {
+        status = hipGetDevice(&prev);
+        if (status == hipSuccess && want >= 0 && want != prev) {
+            status = hipSetDevice(want);
+            switched = status == hipSuccess;
+        }
+    }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
+// Body of an entry point that takes a handle: null check, the engine's device made current, and
+// any C++ exception of the host side (a failed staging allocation) turned into a status code.
+template <typename H, typename F>
+int entry(H h, F&& body) {
+    if (!h) return fail(FDTD_ERR_ARG, "null handle");
+    try {
+        DeviceScope scope(h->device);
+        if (scope.status != hipSuccess) return fail(FDTD_ERR_HIP, "cannot select device %d: %s", h->device, hipGetErrorString(scope.status));
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(FDTD_ERR_HOST, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(FDTD_ERR_HOST, "%s", e.what());
+    }
+}
 
 // ---- device vocabulary ------------------------------------------------------------------
 constexpr int kLanes = 64;        // CDNA wavefront

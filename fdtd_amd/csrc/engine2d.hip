@@ -68,6 +68,7 @@ struct fdtd2d_engine {
     virtual int probe_reset(int drop_probes) = 0;
     fdtd2d_desc d;
     KernelTimer timer;
+    int device = -1;                 // HIP device the state lives on
 };
 
 namespace {
@@ -452,29 +453,44 @@ int fdtd2d_create(const fdtd2d_desc* d, fdtd2d_handle* out) {
     // wall column this engine does not store, so a source there is refused instead of dropped
     if (d->i_Jy == d->Nx) return fail(FDTD_ERR_ARG, "source column i_Jy = Nx lies on the wall");
     if (!(d->dx > 0 && d->dz > 0 && d->dt > 0 && d->mu0 > 0 && d->eps0 > 0)) return fail(FDTD_ERR_ARG, "dx, dz, dt, mu0, eps0 must be positive");
-    if (d->device >= 0) FDTD_HIP(hipSetDevice(d->device));
     int ndev = 0;
     FDTD_HIP(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(FDTD_ERR_HIP, "no HIP device visible");
-    int rc;
-    if (d->precision == 32) { auto e = std::make_unique<Engine2<float>>(); if ((rc = e->init(*d))) return rc; *out = e.release(); }
-    else { auto e = std::make_unique<Engine2<double>>(); if ((rc = e->init(*d))) return rc; *out = e.release(); }
+    if (d->device >= ndev) return fail(FDTD_ERR_ARG, "device %d requested, %d visible", d->device, ndev);
+    try {
+        DeviceScope scope(d->device);
+        if (scope.status != hipSuccess) return fail(FDTD_ERR_HIP, "cannot select device %d: %s", d->device, hipGetErrorString(scope.status));
+        int dev = 0, rc;
+        FDTD_HIP(hipGetDevice(&dev));
+        if (d->precision == 32) { auto e = std::make_unique<Engine2<float>>(); e->device = dev; if ((rc = e->init(*d))) return rc; *out = e.release(); }
+        else { auto e = std::make_unique<Engine2<double>>(); e->device = dev; if ((rc = e->init(*d))) return rc; *out = e.release(); }
+    } catch (const std::bad_alloc&) {
+        return fail(FDTD_ERR_HOST, "out of host memory");
+    }
     return FDTD_OK;
 }
-int fdtd2d_destroy(fdtd2d_handle h) { delete h; return FDTD_OK; }
+int fdtd2d_destroy(fdtd2d_handle h) {
+    if (!h) return FDTD_OK;
+    DeviceScope scope(h->device);
+    delete h;
+    return FDTD_OK;
+}
 size_t fdtd2d_array_size(fdtd2d_handle h, int id) { return h ? h->array_size(id) : 0; }
-int fdtd2d_set_array(fdtd2d_handle h, int id, const double* host, size_t n) { return h ? h->set_array(id, host, n) : fail(FDTD_ERR_ARG, "null handle"); }
-int fdtd2d_get_array(fdtd2d_handle h, int id, double* host, size_t n) { return h ? h->get_array(id, host, n) : fail(FDTD_ERR_ARG, "null handle"); }
-int fdtd2d_step(fdtd2d_handle h, int n0, int count, void* stream) { return h ? h->step(n0, count, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
-int fdtd2d_sumsq(fdtd2d_handle h, int id, double* out, void* stream) { return (h && out) ? h->sumsq(id, out, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null argument"); }
+int fdtd2d_set_array(fdtd2d_handle h, int id, const double* host, size_t n) { return entry(h, [&] { return h->set_array(id, host, n); }); }
+int fdtd2d_get_array(fdtd2d_handle h, int id, double* host, size_t n) { return entry(h, [&] { return h->get_array(id, host, n); }); }
+int fdtd2d_step(fdtd2d_handle h, int n0, int count, void* stream) { return entry(h, [&] { return h->step(n0, count, (hipStream_t)stream); }); }
+int fdtd2d_sumsq(fdtd2d_handle h, int id, double* out, void* stream) {
+    if (!out) return fail(FDTD_ERR_ARG, "null argument");
+    return entry(h, [&] { return h->sumsq(id, out, (hipStream_t)stream); });
+}
 size_t fdtd2d_device_bytes(fdtd2d_handle h) { return h ? h->device_bytes() : 0; }
-int fdtd2d_observe_accumulate(fdtd2d_handle h, double weight, int reset, void* stream) { return h ? h->observe_accumulate(weight, reset, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
-int fdtd2d_observe_rms(fdtd2d_handle h, double* host, size_t n) { return h ? h->observe_rms(host, n) : fail(FDTD_ERR_ARG, "null handle"); }
-int fdtd2d_probe_add(fdtd2d_handle h, int id, int i, int k) { return h ? h->probe_add(id, i, k) : fail(FDTD_ERR_ARG, "null handle"); }
-int fdtd2d_probe_record(fdtd2d_handle h, void* stream) { return h ? h->probe_record((hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
-int fdtd2d_probe_read(fdtd2d_handle h, double* out, size_t cap, int* n_samples, int* n_probes) { return h ? h->probe_read(out, cap, n_samples, n_probes) : fail(FDTD_ERR_ARG, "null handle"); }
-int fdtd2d_probe_reset(fdtd2d_handle h, int drop_probes) { return h ? h->probe_reset(drop_probes) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd2d_observe_accumulate(fdtd2d_handle h, double weight, int reset, void* stream) { return entry(h, [&] { return h->observe_accumulate(weight, reset, (hipStream_t)stream); }); }
+int fdtd2d_observe_rms(fdtd2d_handle h, double* host, size_t n) { return entry(h, [&] { return h->observe_rms(host, n); }); }
+int fdtd2d_probe_add(fdtd2d_handle h, int id, int i, int k) { return entry(h, [&] { return h->probe_add(id, i, k); }); }
+int fdtd2d_probe_record(fdtd2d_handle h, void* stream) { return entry(h, [&] { return h->probe_record((hipStream_t)stream); }); }
+int fdtd2d_probe_read(fdtd2d_handle h, double* out, size_t cap, int* n_samples, int* n_probes) { return entry(h, [&] { return h->probe_read(out, cap, n_samples, n_probes); }); }
+int fdtd2d_probe_reset(fdtd2d_handle h, int drop_probes) { return entry(h, [&] { return h->probe_reset(drop_probes); }); }
 int fdtd2d_kernel_timing(fdtd2d_handle h, int enable) { if (!h) return fail(FDTD_ERR_ARG, "null handle"); h->timer.enabled = enable != 0; return FDTD_OK; }
-int fdtd2d_kernel_time(fdtd2d_handle h, int kind, int* launches, double* total_ms) { return h ? h->timer.collect(kind, launches, total_ms) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd2d_kernel_time(fdtd2d_handle h, int kind, int* launches, double* total_ms) { return entry(h, [&] { return h->timer.collect(kind, launches, total_ms); }); }
 
 }  // extern "C"

@@ -171,6 +171,7 @@ struct fdtd3d_engine {
     virtual int observe_frame(double* ex_center, double* e_mag, size_t n, hipStream_t s) = 0;
     fdtd3d_desc d;
     KernelTimer timer;
+    int device = -1;                 // HIP device the state lives on
 };
 
 namespace {
@@ -270,20 +271,23 @@ struct Engine3 : fdtd3d_engine {
     }
     // Four steps with the source off on the all-zero state: timing only, the state stays zero.
     int probe(double* ms_per_step) {
-        hipEvent_t e0, e1;
-        FDTD_HIP(hipEventCreate(&e0)); FDTD_HIP(hipEventCreate(&e1));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        FDTD_HIP(hipEventCreate(&e0));
+        if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(FDTD_ERR_HIP, "hipEventCreate failed"); }
         const int n_off = (int)wf.size();          // past the waveform: no source term
         int rc = step(n_off, 0);                   // warm-up: code objects, first touch
         if (!rc) rc = step(n_off, 0);
-        FDTD_HIP(hipEventRecord(e0, 0));
-        for (int q = 0; q < 4 && !rc; ++q) rc = step(n_off, 0);
-        FDTD_HIP(hipEventRecord(e1, 0));
-        FDTD_HIP(hipEventSynchronize(e1));
         float ms = 0;
-        FDTD_HIP(hipEventElapsedTime(&ms, e0, e1));
+        hipError_t he = hipEventRecord(e0, 0);
+        for (int q = 0; q < 4 && !rc; ++q) rc = step(n_off, 0);
+        if (he == hipSuccess) he = hipEventRecord(e1, 0);
+        if (he == hipSuccess) he = hipEventSynchronize(e1);
+        if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        if (rc) return rc;
+        if (he != hipSuccess) return fail(FDTD_ERR_HIP, "timing a placement failed: %s", hipGetErrorString(he));
         *ms_per_step = ms / 4;
-        return rc;
+        return FDTD_OK;
     }
 
     int allocate_all() {
@@ -857,72 +861,87 @@ int fdtd3d_create(const fdtd3d_desc* desc, fdtd3d_handle* out) {
     if (!out) return fail(FDTD_ERR_ARG, "null output handle");
     *out = nullptr;
     if (int rc = check_desc(desc)) return rc;
-    if (desc->device >= 0) FDTD_HIP(hipSetDevice(desc->device));
     int ndev = 0;
     FDTD_HIP(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(FDTD_ERR_HIP, "no HIP device visible");
-    int rc;
-    if (desc->precision == 32) {
-        auto e = std::make_unique<Engine3<float>>();
-        if ((rc = e->init(*desc))) return rc;
-        *out = e.release();
-    } else {
-        auto e = std::make_unique<Engine3<double>>();
-        if ((rc = e->init(*desc))) return rc;
-        *out = e.release();
+    if (desc->device >= ndev) return fail(FDTD_ERR_ARG, "device %d requested, %d visible", desc->device, ndev);
+    try {
+        DeviceScope scope(desc->device);
+        if (scope.status != hipSuccess) return fail(FDTD_ERR_HIP, "cannot select device %d: %s", desc->device, hipGetErrorString(scope.status));
+        int dev = 0;
+        FDTD_HIP(hipGetDevice(&dev));
+        int rc;
+        if (desc->precision == 32) {
+            auto e = std::make_unique<Engine3<float>>();
+            e->device = dev;
+            if ((rc = e->init(*desc))) return rc;
+            *out = e.release();
+        } else {
+            auto e = std::make_unique<Engine3<double>>();
+            e->device = dev;
+            if ((rc = e->init(*desc))) return rc;
+            *out = e.release();
+        }
+    } catch (const std::bad_alloc&) {
+        return fail(FDTD_ERR_HOST, "out of host memory");
     }
     return FDTD_OK;
 }
-int fdtd3d_destroy(fdtd3d_handle h) { delete h; return FDTD_OK; }
+int fdtd3d_destroy(fdtd3d_handle h) {
+    if (!h) return FDTD_OK;
+    DeviceScope scope(h->device);
+    delete h;
+    return FDTD_OK;
+}
 size_t fdtd3d_array_size(fdtd3d_handle h, int id) { return h ? h->array_size(id) : 0; }
-int fdtd3d_set_array(fdtd3d_handle h, int id, const double* host, size_t n) { return h ? h->set_array(id, host, n) : fail(FDTD_ERR_ARG, "null handle"); }
-int fdtd3d_get_array(fdtd3d_handle h, int id, double* host, size_t n) { return h ? h->get_array(id, host, n) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_set_array(fdtd3d_handle h, int id, const double* host, size_t n) { return entry(h, [&] { return h->set_array(id, host, n); }); }
+int fdtd3d_get_array(fdtd3d_handle h, int id, double* host, size_t n) { return entry(h, [&] { return h->get_array(id, host, n); }); }
 int fdtd3d_fill_materials(fdtd3d_handle h, uint64_t seed, double elo, double ehi, double mlo, double mhi) {
-    return h ? h->fill_materials(seed, elo, ehi, mlo, mhi) : fail(FDTD_ERR_ARG, "null handle");
+    return entry(h, [&] { return h->fill_materials(seed, elo, ehi, mlo, mhi); });
 }
-int fdtd3d_fill_reference_materials(fdtd3d_handle h) { return h ? h->fill_reference_materials() : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_fill_reference_materials(fdtd3d_handle h) { return entry(h, [&] { return h->fill_reference_materials(); }); }
 int fdtd3d_step(fdtd3d_handle h, int n0, int count, void* stream) {
-    if (!h) return fail(FDTD_ERR_ARG, "null handle");
-    if (h->d.z_lo != 0 || h->d.z_hi != h->d.Nz) return fail(FDTD_ERR_STATE, "fdtd3d_step needs the whole grid on this device; slab drivers use fdtd3d_half_e / fdtd3d_half_h");
-    for (int n = n0; n < n0 + count; ++n) {
-        if (int rc = h->step(n, (hipStream_t)stream)) return rc;
-        if (int rc = h->probe_record((hipStream_t)stream)) return rc;
-    }
-    return FDTD_OK;
+    return entry(h, [&]() -> int {
+        if (h->d.z_lo != 0 || h->d.z_hi != h->d.Nz) return fail(FDTD_ERR_STATE, "fdtd3d_step needs the whole grid on this device; slab drivers use fdtd3d_half_e / fdtd3d_half_h or fdtd3d_fused");
+        for (int n = n0; n < n0 + count; ++n) {
+            if (int rc = h->step(n, (hipStream_t)stream)) return rc;
+            if (int rc = h->probe_record((hipStream_t)stream)) return rc;
+        }
+        return FDTD_OK;
+    });
 }
-int fdtd3d_fused(fdtd3d_handle h, int n, int part, void* stream) { return h ? h->fused_part(n, part, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
-int fdtd3d_fused_top(fdtd3d_handle h, void* stream) { return h ? h->fused_top((hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
-int fdtd3d_probe_add(fdtd3d_handle h, int id, int i, int j, int k) { return h ? h->probe_add(id, i, j, k) : fail(FDTD_ERR_ARG, "null handle"); }
-int fdtd3d_probe_record(fdtd3d_handle h, void* stream) { return h ? h->probe_record((hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
-int fdtd3d_probe_read(fdtd3d_handle h, double* out, size_t cap, int* n_samples, int* n_probes) { return h ? h->probe_read(out, cap, n_samples, n_probes) : fail(FDTD_ERR_ARG, "null handle"); }
-int fdtd3d_probe_reset(fdtd3d_handle h, int drop_probes) { return h ? h->probe_reset(drop_probes) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_fused(fdtd3d_handle h, int n, int part, void* stream) { return entry(h, [&] { return h->fused_part(n, part, (hipStream_t)stream); }); }
+int fdtd3d_fused_top(fdtd3d_handle h, void* stream) { return entry(h, [&] { return h->fused_top((hipStream_t)stream); }); }
+int fdtd3d_probe_add(fdtd3d_handle h, int id, int i, int j, int k) { return entry(h, [&] { return h->probe_add(id, i, j, k); }); }
+int fdtd3d_probe_record(fdtd3d_handle h, void* stream) { return entry(h, [&] { return h->probe_record((hipStream_t)stream); }); }
+int fdtd3d_probe_read(fdtd3d_handle h, double* out, size_t cap, int* n_samples, int* n_probes) { return entry(h, [&] { return h->probe_read(out, cap, n_samples, n_probes); }); }
+int fdtd3d_probe_reset(fdtd3d_handle h, int drop_probes) { return entry(h, [&] { return h->probe_reset(drop_probes); }); }
 int fdtd3d_placement_probes(fdtd3d_handle h, double* ms, int cap) { return (h && (ms || cap == 0)) ? h->placement(ms, cap) : 0; }
 int fdtd3d_buffer_parity(fdtd3d_handle h) { return h ? h->parity() : 0; }
-int fdtd3d_half_e(fdtd3d_handle h, int n, int part, void* stream) { return h ? h->half_e(n, part, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
-int fdtd3d_half_h(fdtd3d_handle h, int part, void* stream) { return h ? h->half_h(part, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_half_e(fdtd3d_handle h, int n, int part, void* stream) { return entry(h, [&] { return h->half_e(n, part, (hipStream_t)stream); }); }
+int fdtd3d_half_h(fdtd3d_handle h, int part, void* stream) { return entry(h, [&] { return h->half_h(part, (hipStream_t)stream); }); }
 int fdtd3d_halo(fdtd3d_handle h, int which, int comp, void** p, size_t* bytes) {
     if (!h || !p || !bytes) return fail(FDTD_ERR_ARG, "null argument");
-    return h->halo(which, comp, p, bytes, -1);
+    return h->halo(which, comp, p, bytes, -1);         // pointer arithmetic only: no device call
 }
 int fdtd3d_halo_at(fdtd3d_handle h, int parity, int which, int comp, void** p, size_t* bytes) {
     if (!h || !p || !bytes || parity < 0 || parity > 1) return fail(FDTD_ERR_ARG, "bad argument");
     return h->halo(which, comp, p, bytes, parity);
 }
-int fdtd3d_sumsq(fdtd3d_handle h, int id, double* out, void* stream) { return h ? h->reduce(id, out, nullptr, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
-int fdtd3d_checksum(fdtd3d_handle h, int id, uint64_t* out, void* stream) { return h ? h->reduce(id, nullptr, out, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_sumsq(fdtd3d_handle h, int id, double* out, void* stream) { return entry(h, [&] { return h->reduce(id, out, nullptr, (hipStream_t)stream); }); }
+int fdtd3d_checksum(fdtd3d_handle h, int id, uint64_t* out, void* stream) { return entry(h, [&] { return h->reduce(id, nullptr, out, (hipStream_t)stream); }); }
 size_t fdtd3d_device_bytes(fdtd3d_handle h) { return h ? h->device_bytes() : 0; }
-int fdtd3d_tune(fdtd3d_handle h, int chunk, int remap, int rows) { return h ? h->tune(chunk, remap, rows) : fail(FDTD_ERR_ARG, "null handle"); }
-int fdtd3d_observe_accumulate(fdtd3d_handle h, double weight, int reset, void* stream) { return h ? h->observe_accumulate(weight, reset, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
-int fdtd3d_observe_rms(fdtd3d_handle h, double* host, size_t n) { return h ? h->observe_rms(host, n) : fail(FDTD_ERR_ARG, "null handle"); }
-int fdtd3d_observe_frame(fdtd3d_handle h, double* ex_center, double* e_mag, size_t n, void* stream) { return h ? h->observe_frame(ex_center, e_mag, n, (hipStream_t)stream) : fail(FDTD_ERR_ARG, "null handle"); }
+int fdtd3d_tune(fdtd3d_handle h, int chunk, int remap, int rows) { return entry(h, [&] { return h->tune(chunk, remap, rows); }); }
+int fdtd3d_observe_accumulate(fdtd3d_handle h, double weight, int reset, void* stream) { return entry(h, [&] { return h->observe_accumulate(weight, reset, (hipStream_t)stream); }); }
+int fdtd3d_observe_rms(fdtd3d_handle h, double* host, size_t n) { return entry(h, [&] { return h->observe_rms(host, n); }); }
+int fdtd3d_observe_frame(fdtd3d_handle h, double* ex_center, double* e_mag, size_t n, void* stream) { return entry(h, [&] { return h->observe_frame(ex_center, e_mag, n, (hipStream_t)stream); }); }
 int fdtd3d_kernel_timing(fdtd3d_handle h, int enable) {
     if (!h) return fail(FDTD_ERR_ARG, "null handle");
     h->timer.enabled = enable != 0;
     return FDTD_OK;
 }
 int fdtd3d_kernel_time(fdtd3d_handle h, int kind, int* launches, double* total_ms) {
-    if (!h) return fail(FDTD_ERR_ARG, "null handle");
-    return h->timer.collect(kind, launches, total_ms);
+    return entry(h, [&] { return h->timer.collect(kind, launches, total_ms); });
 }
 
 }  // extern "C"

@@ -33,6 +33,7 @@ extern "C" {
 #define FDTD_ERR_ARG 1      /* bad descriptor / id / size                      */
 #define FDTD_ERR_HIP 2      /* a HIP runtime call failed (message has details) */
 #define FDTD_ERR_STATE 3    /* call not valid for this handle                  */
+#define FDTD_ERR_HOST 4     /* host side failed (out of memory while staging)  */
 
 /* Message for the last failing call on this thread ("" if none). */
 const char* fdtd_last_error(void);
@@ -83,7 +84,7 @@ typedef struct fdtd3d_desc {
     int32_t has_mu;           /* 0: H = B/mu0 (reference), 1: H = B/mu_{x,y,z}               */
     int32_t mode;             /* FDTD3D_MODE_*                                               */
     int32_t z_lo, z_hi;       /* owned cell layers [z_lo, z_hi); 0,Nz = whole grid           */
-    int32_t device;           /* HIP device ordinal, -1 = current                            */
+    int32_t device;           /* HIP device ordinal, -1 = the calling thread's current one   */
     double dx, dy, dz, dt;    /* FDTD3D.h:26-28                                              */
     double mu0;               /* FDTD3D.h:20                                                 */
 } fdtd3d_desc;
@@ -92,7 +93,10 @@ typedef struct fdtd3d_engine* fdtd3d_handle;
 
 /* Allocate device state for one z-slab (fields and CPML auxiliaries zero, eps/mu = 1,
  * tables/source empty).  Replaces the allocations of FDTD3D::setupGrid()/setupPML()
- * (FDTD3D.cpp:41-63, :419-462). */
+ * (FDTD3D.cpp:41-63, :419-462).  The handle remembers its device: every later call makes that
+ * device current for its own duration and puts the caller's device back before it returns, so
+ * handles on several devices may be driven from one thread.  Streams passed to a call must
+ * belong to the handle's device. */
 int fdtd3d_create(const fdtd3d_desc* desc, fdtd3d_handle* out);
 int fdtd3d_destroy(fdtd3d_handle h);
 

@@ -1,0 +1,101 @@
+"""Error behaviour of the C ABI: the reference's solvers have no error path (private void members,
+fdtd3d/include/FDTD3D.h:190-195, fdtd2d/include/FDTD2D.h:88-89), so every refusal here is one the
+boundary adds; each must come back as a status code with a message, never as a crash."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import fdtd_amd
+from fdtd_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+
+MU0 = 4e-7 * np.pi
+GOOD3 = dict(N=(24, 20, 28), npml=(4,) * 6, d=(5e-8,) * 3, dt=8e-17, mu0=MU0, k_Jx=6, n_wf=8)
+
+
+def make3(**over):
+    kw = dict(GOOD3, **over)
+    return fdtd_amd.Engine3D(kw["N"], kw["npml"], kw["d"], kw["dt"], kw["mu0"], kw["k_Jx"], kw["n_wf"],
+                             precision=kw.get("precision", 32), has_mu=kw.get("has_mu", False),
+                             mode=kw.get("mode", E.MODE_FULL), z_range=kw.get("z_range"), device=kw.get("device", -1))
+
+
+@pytest.mark.parametrize("over, word", [
+    (dict(precision=16), "precision"),
+    (dict(N=(1, 20, 28)), "too small"),
+    (dict(npml=(12, 12, 4, 4, 4, 4)), "do not fit"),
+    (dict(npml=(4, 4, 4, 4, 4, 65)), "CPML layer counts"),
+    (dict(z_range=(10, 10)), "bad slab"),
+    (dict(z_range=(0, 29)), "bad slab"),
+    (dict(k_Jx=29), "source plane"),
+    (dict(mode=7), "storage mode"),
+    (dict(dt=0.0), "positive"),
+    (dict(device=4096), "device"),
+])
+def test_bad_descriptors_are_refused_3d(over, word):
+    with pytest.raises(E.EngineError, match=word):
+        make3(**over)
+
+
+def test_descriptor_size_is_checked():
+    L = E.lib()
+    desc = E.Desc3D(C.sizeof(E.Desc3D) - 8, 24, 20, 28, (C.c_int32 * 6)(4, 4, 4, 4, 4, 4), 6, 8, 32, 0, 0, 0, 28, -1, 5e-8, 5e-8, 5e-8, 8e-17, MU0)
+    h = C.c_void_p()
+    assert L.fdtd3d_create(C.byref(desc), C.byref(h)) == 1 and not h.value
+    assert b"descriptor size" in L.fdtd_last_error()
+    d2 = E.Desc2D(4, 32, 32, (C.c_int32 * 4)(4, 4, 4, 4), 16, 16, 8, 32, -1, 5e-8, 5e-8, 8e-17, MU0, 8.854e-12, 0, 0)
+    assert L.fdtd2d_create(C.byref(d2), C.byref(h)) == 1 and not h.value
+
+
+def test_null_handles_and_null_outputs():
+    L = E.lib()
+    null = C.c_void_p(0)
+    assert L.fdtd3d_step(null, 0, 1, None) == 1
+    assert L.fdtd3d_half_e(null, 0, 0, None) == 1
+    assert L.fdtd2d_step(null, 0, 1, None) == 1
+    assert L.fdtd3d_array_size(null, 0) == 0
+    assert L.fdtd3d_destroy(null) == 0 and L.fdtd2d_destroy(null) == 0
+    assert L.fdtd3d_create(None, C.byref(null)) == 1
+    assert b"null" in L.fdtd_last_error()
+
+
+def test_array_exchange_refusals_3d():
+    eng = make3(mode=E.MODE_LEAN)
+    with pytest.raises(E.EngineError, match="expected"):
+        eng.set(E.DX, np.zeros(5))
+    assert E.lib().fdtd3d_set_array(eng.h, 999, None, C.c_size_t(0)) == 1
+    assert b"unknown array id" in E.lib().fdtd_last_error()
+    with pytest.raises(E.EngineError, match="not resident"):
+        eng.set(E.EX, np.zeros(eng.size(E.EX)))
+    assert eng.size(E.MU_X) == 0                       # no mu grid on this engine
+    with pytest.raises(E.EngineError):
+        eng.fused(0)                                   # not a FUSED engine
+    with pytest.raises(E.EngineError, match="bad part"):
+        eng.half_e(0, part=9)
+
+
+def test_bad_descriptors_are_refused_2d():
+    def make(**over):
+        kw = dict(Nx=40, Nz=48, npml=(4, 4, 4, 4), dx=5e-8, dz=5e-8, dt=8e-17, mu0=MU0, eps0=8.854e-12, i_Jy=20, k_Jy=10, n_wf=8)
+        kw.update(over)
+        return fdtd_amd.Engine2D(kw["Nx"], kw["Nz"], kw["npml"], kw["dx"], kw["dz"], kw["dt"], kw["mu0"], kw["eps0"],
+                                 kw["i_Jy"], kw["k_Jy"], kw["n_wf"], precision=kw.get("precision", 32), mode=kw.get("mode", 0),
+                                 device=kw.get("device", -1))
+    make().close()
+    for over, word in [(dict(precision=8), "precision"), (dict(mode=3), "mode"), (dict(Nx=1), "too small"),
+                       (dict(npml=(20, 20, 4, 4)), "do not fit"), (dict(i_Jy=40), "wall"), (dict(eps0=0.0), "positive"),
+                       (dict(device=4096), "device")]:
+        with pytest.raises(E.EngineError, match=word):
+            make(**over)
+
+
+def test_calls_leave_the_callers_device_current():
+    import torch
+    before = torch.cuda.current_device()
+    eng = make3(device=0, mode=E.MODE_FUSED)
+    eng.step(0, 2)
+    eng.get(E.DX)
+    assert torch.cuda.current_device() == before
+    eng.close()
