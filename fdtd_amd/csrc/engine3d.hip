@@ -354,7 +354,7 @@ struct Engine3 : fdtd3d_engine {
         // in 18.1, 18.9 or 20.0 ms, cycling with every free + allocate, across processes).  For large
         // grids the arena is therefore placed a few times, each placement timed with four source-free
         // steps on the zero state (which they leave unchanged); after three placements the first one in
-        // the fast third of the range seen so far is kept (an earlier placement cannot be returned to).
+        // the fast fifth of the range seen so far is kept (an earlier placement cannot be returned to).
         int tries = arena_cap >= ((size_t)8 << 30) ? 8 : 1;
         if (const char* e = getenv("FDTD_PLACEMENT_TRIES")) { int v = atoi(e); if (v >= 1 && v <= 16) tries = v; }
         int explore = 3;                 // placements timed before the first may be accepted
@@ -371,7 +371,7 @@ struct Engine3 : fdtd3d_engine {
             const bool explored = t + 1 >= explore || t + 1 >= tries;
             best = std::min(best, ms); worst = std::max(worst, ms);
             placement_log.push_back(ms);
-            if ((explored && ms <= std::max(best * 1.005, best + 0.35 * (worst - best))) || t + 1 >= tries) break;
+            if ((explored && ms <= std::max(best * 1.005, best + 0.2 * (worst - best))) || t + 1 >= tries) break;
             FDTD_HIP(hipFree(arena));
             allocs.clear(); arena = nullptr;
         }

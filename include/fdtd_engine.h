@@ -200,7 +200,7 @@ int fdtd3d_probe_reset(fdtd3d_handle h, int drop_probes);
 /* Large engines (>= 8 GiB of device state) are placed in device memory up to FDTD_PLACEMENT_TRIES
  * times (environment, default 8, 1 = off) at creation: where the driver puts a large allocation
  * changes the streaming rate of the step kernels by several percent, so each placement is timed with
- * a few source-free steps on the zero state and, after three, the first one in the fast third of the
+ * a few source-free steps on the zero state and, after three, the first one in the fast fifth of the
  * range seen is kept.
  * Returns how many placements were timed and copies up to `cap` of their step times (ms). */
 int fdtd3d_placement_probes(fdtd3d_handle h, double* ms_per_step, int cap);
