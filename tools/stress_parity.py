@@ -1,0 +1,33 @@
+"""The suite's randomized parity tests (fused and two-kernel, 3-D whole grids and slab partitions, 2-D)
+over a range of further seeds:  python tools/stress_parity.py LO HI   (needs the GPU; ~8 seeds per second)."""
+import sys, time, traceback
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests import test_gpu_fused as tf, test_gpu_fused2d as t2, test_gpu_parity as tp
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+bad = 0
+t0 = time.time()
+for seed in range(lo, hi):
+    for name, fn in (("fused3d", tf.test_fused_random_configurations_equal_twin), ("slabs3d", tf.test_fused_random_slab_partitions_equal_twin)):
+        try:
+            fn(seed)
+        except Exception as e:
+            bad += 1
+            print(f"FAIL {name} seed {seed}: {str(e)[:300]}", flush=True)
+    for name, fn in (("fused2d", getattr(t2, "test_fused2d_random_configurations_equal_twin", None)), ("2d", tp.test_random_configurations_2d_equal_twin)):
+        if fn is None: continue
+        try:
+            fn(seed)
+        except Exception as e:
+            bad += 1
+            print(f"FAIL {name} seed {seed}: {str(e)[:300]}", flush=True)
+    for mode in (0, 1):
+        try:
+            tp.test_random_configurations_half_step_kernels_equal_twin(seed, mode)
+        except Exception as e:
+            bad += 1
+            print(f"FAIL half mode {mode} seed {seed}: {str(e)[:300]}", flush=True)
+    if seed % 10 == 0:
+        print(f"seed {seed} done, {bad} failures, {time.time()-t0:.0f}s", flush=True)
+print("failures:", bad)
+sys.exit(1 if bad else 0)
