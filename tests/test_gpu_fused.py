@@ -1,4 +1,6 @@
 """One-kernel-per-step (fused E+H) stepping against the golden vectors and the twin (needs a GPU)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -242,7 +244,13 @@ def test_fused_random_configurations_equal_twin(seed):
     dt = 5e-8 / (2 * K["c0"])
     steps = 13
     kJ = int(rng.integers(0, N[2] + 1))
-    eng = fdtd_amd.Engine3D(N, npml, d, dt, K["mu0"], kJ, steps, precision=prec, mode=MODE_FUSED, has_mu=has_mu)
+    narrow = seed % 3 == 2               # every third case: half-width lanes (8 bytes per lane instead of 16)
+    if narrow:
+        os.environ["FDTD_FUSED_VEC"] = "2" if prec == 32 else "1"
+    try:
+        eng = fdtd_amd.Engine3D(N, npml, d, dt, K["mu0"], kJ, steps, precision=prec, mode=MODE_FUSED, has_mu=has_mu)
+    finally:
+        os.environ.pop("FDTD_FUSED_VEC", None)
     eng.tune(chunk, int(rng.integers(0, 2)), rows)
     tw = po.Twin3D(prec, N, npml, d, dt, K["mu0"], kJ, steps, has_mu)
     wf = rng.standard_normal(steps)
