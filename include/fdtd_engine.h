@@ -212,7 +212,8 @@ size_t fdtd3d_device_bytes(fdtd3d_handle h);
  * tile order (0/1), rows (= waves) per workgroup (1..4 for the half-step kernels; 2..16 for the
  * fused kernel, whose last wave recomputes the first row of the next tile); a value outside its
  * range keeps the current setting.  The environment variables FDTD_Z_CHUNK / FDTD_XCD_REMAP / FDTD_ROWS_PER_GROUP
- * set them at creation. */
+ * set them at creation; FDTD_FUSED_VEC (elements per lane of the fused kernel: 4 or 2 in fp32, 2 or 1
+ * in fp64) can only be chosen there. */
 int fdtd3d_tune(fdtd3d_handle h, int chunk, int remap, int rows);
 
 /* Timing hook for the dominant kernels: if enabled, every E-half / H-half launch is
