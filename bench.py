@@ -228,6 +228,7 @@ def main():
                        "device_bytes_per_gpu": eng.device_bytes(), "placement_probe_ms": [round(v, 3) for v in eng.placement_probes()]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_rate_GBs": (traffic / t_dom / 1e9) if traffic else None,   # bytes really moved per second
                          "algorithmic_bytes_per_launch": cells_local * dom_bytes,
                          "algorithmic_bytes_per_cell": dom_bytes,
                          "cells_per_launch": cells_local,
