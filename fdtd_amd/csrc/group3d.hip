@@ -1,0 +1,280 @@
+// group3d.hip -- several z-slab engines of one 3-D problem driven from ONE host thread: the slab
+// choreography (edge planes first, ghost planes copied device to device while the bulk is computed)
+// on HIP streams and events, written against the library's own C ABI.  The reference steps its whole
+// grid from one thread (FDTD3D::run, fdtd3d/src/FDTD3D.cpp:1085-1086); this is that loop for a grid
+// spread over the GPUs of one node, for callers that do not want one process per GPU.
+#include "common.hpp"
+
+#include <memory>
+
+using namespace fdtd;
+
+struct fdtd3d_group {
+    fdtd3d_desc d{};
+    bool fused = false;
+    std::vector<fdtd3d_handle> member;          // bottom slab first
+    std::vector<int> device;
+    // per member: the stream its kernels run on, and the streams that carry its planes to the slab
+    // above (up) and below (down); all blocking streams, so that calls on a member's device through
+    // the null stream (downloads, observables) order themselves behind the step
+    std::vector<hipStream_t> run, up, down;
+    // per member: lowest planes done (also: low ghost consumed), top layer done (also: high ghost
+    // consumed), D/E ghost from above arrived, B/H ghost from below arrived
+    std::vector<hipEvent_t> edge_done, top_done, hi_here, lo_here;
+
+    ~fdtd3d_group() {
+        for (size_t r = 0; r < member.size(); ++r) {
+            DeviceScope scope(device[r]);
+            (void)hipDeviceSynchronize();
+        }
+        for (size_t r = 0; r < member.size(); ++r) {
+            DeviceScope scope(device[r]);
+            for (auto* v : {&run, &up, &down}) if (r < v->size() && (*v)[r]) (void)hipStreamDestroy((*v)[r]);
+            for (auto* v : {&edge_done, &top_done, &hi_here, &lo_here}) if (r < v->size() && (*v)[r]) (void)hipEventDestroy((*v)[r]);
+            if (member[r]) fdtd3d_destroy(member[r]);
+        }
+    }
+};
+
+namespace {
+
+// One x-y plane pair (components 0 and 1) from `src`'s send planes into `dst`'s ghost planes, on
+// `stream` (a stream of the source's device, which must be current).
+int copy_planes(fdtd3d_group* g, int src, int which_src, int dst, int which_dst, int parity, hipStream_t stream) {
+    for (int c = 0; c < 2; ++c) {
+        void *from = nullptr, *to = nullptr;
+        size_t nb = 0, nb2 = 0;
+        int rc = g->fused ? fdtd3d_halo_at(g->member[src], parity, which_src, c, &from, &nb) : fdtd3d_halo(g->member[src], which_src, c, &from, &nb);
+        if (rc) return rc;
+        rc = g->fused ? fdtd3d_halo_at(g->member[dst], parity, which_dst, c, &to, &nb2) : fdtd3d_halo(g->member[dst], which_dst, c, &to, &nb2);
+        if (rc) return rc;
+        if (nb != nb2) return fail(FDTD_ERR_STATE, "group: ghost planes of slabs %d and %d differ in size", src, dst);
+        if (g->device[src] == g->device[dst]) FDTD_HIP(hipMemcpyAsync(to, from, nb, hipMemcpyDeviceToDevice, stream));
+        else FDTD_HIP(hipMemcpyPeerAsync(to, g->device[dst], from, g->device[src], nb, stream));
+    }
+    return FDTD_OK;
+}
+
+// Step n with the fused kernel.  Order per slab: lowest planes (their D starts travelling down), highest
+// planes, top layer's B once the D plane from above is there (it starts travelling up), then the bulk.
+int step_fused(fdtd3d_group* g, int n) {
+    const int R = (int)g->member.size();
+    int rc;
+    for (int r = 0; r < R; ++r) {
+        DeviceScope scope(g->device[r]);
+        if (r > 0) FDTD_HIP(hipStreamWaitEvent(g->run[r], g->lo_here[r], 0));
+        if ((rc = fdtd3d_fused(g->member[r], n, FDTD3D_PART_EDGE, g->run[r]))) return rc;
+        FDTD_HIP(hipEventRecord(g->edge_done[r], g->run[r]));
+    }
+    const int parity = fdtd3d_buffer_parity(g->member[0]);       // all members change buffers together
+    for (int r = 1; r < R; ++r) {
+        DeviceScope scope(g->device[r]);
+        FDTD_HIP(hipStreamWaitEvent(g->down[r], g->edge_done[r], 0));
+        FDTD_HIP(hipStreamWaitEvent(g->down[r], g->top_done[r - 1], 0));     // the ghost's previous content has been used
+        if ((rc = copy_planes(g, r, FDTD3D_HALO_SEND_DOWN, r - 1, FDTD3D_HALO_RECV_HI, parity, g->down[r]))) return rc;
+        FDTD_HIP(hipEventRecord(g->hi_here[r - 1], g->down[r]));
+    }
+    for (int r = 0; r < R; ++r) {
+        DeviceScope scope(g->device[r]);
+        if ((rc = fdtd3d_fused(g->member[r], n, FDTD3D_PART_TOP, g->run[r]))) return rc;
+        if (r + 1 < R) FDTD_HIP(hipStreamWaitEvent(g->run[r], g->hi_here[r], 0));
+        if ((rc = fdtd3d_fused_top(g->member[r], g->run[r]))) return rc;
+        FDTD_HIP(hipEventRecord(g->top_done[r], g->run[r]));
+    }
+    for (int r = 0; r + 1 < R; ++r) {
+        DeviceScope scope(g->device[r]);
+        FDTD_HIP(hipStreamWaitEvent(g->up[r], g->top_done[r], 0));
+        FDTD_HIP(hipStreamWaitEvent(g->up[r], g->edge_done[r + 1], 0));      // the ghost's previous content has been used
+        if ((rc = copy_planes(g, r, FDTD3D_HALO_SEND_UP, r + 1, FDTD3D_HALO_RECV_LO, parity, g->up[r]))) return rc;
+        FDTD_HIP(hipEventRecord(g->lo_here[r + 1], g->up[r]));
+    }
+    for (int r = 0; r < R; ++r) {
+        DeviceScope scope(g->device[r]);
+        if ((rc = fdtd3d_fused(g->member[r], n, FDTD3D_PART_INTERIOR, g->run[r]))) return rc;
+        if ((rc = fdtd3d_probe_record(g->member[r], g->run[r]))) return rc;
+    }
+    return FDTD_OK;
+}
+
+// Step n with the two half-step kernels (FULL and LEAN storage): the bulk of each half never looks at
+// a ghost plane, so it runs while the plane the edge layer needs is still travelling.
+int step_halves(fdtd3d_group* g, int n) {
+    const int R = (int)g->member.size();
+    int rc;
+    for (int r = 0; r < R; ++r) {
+        DeviceScope scope(g->device[r]);
+        if ((rc = fdtd3d_half_e(g->member[r], n, FDTD3D_PART_INTERIOR, g->run[r]))) return rc;
+        if (r > 0) FDTD_HIP(hipStreamWaitEvent(g->run[r], g->lo_here[r], 0));
+        if ((rc = fdtd3d_half_e(g->member[r], n, FDTD3D_PART_EDGE, g->run[r]))) return rc;
+        FDTD_HIP(hipEventRecord(g->edge_done[r], g->run[r]));
+    }
+    for (int r = 1; r < R; ++r) {
+        DeviceScope scope(g->device[r]);
+        FDTD_HIP(hipStreamWaitEvent(g->down[r], g->edge_done[r], 0));
+        FDTD_HIP(hipStreamWaitEvent(g->down[r], g->top_done[r - 1], 0));
+        if ((rc = copy_planes(g, r, FDTD3D_HALO_SEND_DOWN, r - 1, FDTD3D_HALO_RECV_HI, 0, g->down[r]))) return rc;
+        FDTD_HIP(hipEventRecord(g->hi_here[r - 1], g->down[r]));
+    }
+    for (int r = 0; r < R; ++r) {
+        DeviceScope scope(g->device[r]);
+        if ((rc = fdtd3d_half_h(g->member[r], FDTD3D_PART_INTERIOR, g->run[r]))) return rc;
+        if (r + 1 < R) FDTD_HIP(hipStreamWaitEvent(g->run[r], g->hi_here[r], 0));
+        if ((rc = fdtd3d_half_h(g->member[r], FDTD3D_PART_EDGE, g->run[r]))) return rc;
+        FDTD_HIP(hipEventRecord(g->top_done[r], g->run[r]));
+    }
+    for (int r = 0; r + 1 < R; ++r) {
+        DeviceScope scope(g->device[r]);
+        FDTD_HIP(hipStreamWaitEvent(g->up[r], g->top_done[r], 0));
+        FDTD_HIP(hipStreamWaitEvent(g->up[r], g->edge_done[r + 1], 0));
+        if ((rc = copy_planes(g, r, FDTD3D_HALO_SEND_UP, r + 1, FDTD3D_HALO_RECV_LO, 0, g->up[r]))) return rc;
+        FDTD_HIP(hipEventRecord(g->lo_here[r + 1], g->up[r]));
+    }
+    for (int r = 0; r < R; ++r) {
+        DeviceScope scope(g->device[r]);
+        if ((rc = fdtd3d_probe_record(g->member[r], g->run[r]))) return rc;
+    }
+    return FDTD_OK;
+}
+
+int build_group(fdtd3d_group* g, const fdtd3d_desc* desc, int n_slabs, const int* devices) {
+    g->d = *desc;
+    g->fused = desc->mode == FDTD3D_MODE_FUSED;
+    int ndev = 0;
+    FDTD_HIP(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(FDTD_ERR_HIP, "no HIP device visible");
+    const int base = desc->Nz / n_slabs, extra = desc->Nz % n_slabs;
+    int lo = 0;
+    for (int r = 0; r < n_slabs; ++r) {
+        const int dev = devices ? devices[r] : r % ndev;
+        if (dev < 0 || dev >= ndev) return fail(FDTD_ERR_ARG, "group: slab %d asks for device %d, %d visible", r, dev, ndev);
+        fdtd3d_desc md = *desc;
+        md.z_lo = lo;
+        md.z_hi = lo + base + (r < extra ? 1 : 0);
+        md.device = dev;
+        lo = md.z_hi;
+        g->member.push_back(nullptr);
+        g->device.push_back(dev);
+        if (int rc = fdtd3d_create(&md, &g->member.back())) return rc;
+    }
+    // direct copies between the devices of neighbouring slabs (over xGMI); where the driver refuses,
+    // hipMemcpyPeerAsync still works, staged by the runtime
+    for (int r = 0; r + 1 < n_slabs; ++r) {
+        const int a = g->device[r], b = g->device[r + 1];
+        if (a == b) continue;
+        for (int dir = 0; dir < 2; ++dir) {
+            const int from = dir ? b : a, to = dir ? a : b;
+            DeviceScope scope(from);
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, from, to) == hipSuccess && can && hipDeviceEnablePeerAccess(to, 0) != hipSuccess)
+                (void)hipGetLastError();                 // already enabled by someone else: fine
+        }
+    }
+    const size_t R = (size_t)n_slabs;
+    g->run.assign(R, nullptr); g->up.assign(R, nullptr); g->down.assign(R, nullptr);
+    g->edge_done.assign(R, nullptr); g->top_done.assign(R, nullptr); g->hi_here.assign(R, nullptr); g->lo_here.assign(R, nullptr);
+    for (size_t r = 0; r < R; ++r) {
+        DeviceScope scope(g->device[r]);
+        for (auto* v : {&g->run, &g->up, &g->down}) FDTD_HIP(hipStreamCreate(&(*v)[r]));
+        for (auto* v : {&g->edge_done, &g->top_done, &g->hi_here, &g->lo_here}) FDTD_HIP(hipEventCreateWithFlags(&(*v)[r], hipEventDisableTiming));
+    }
+    return FDTD_OK;
+}
+
+template <typename F>
+int each_member(fdtd3d_group_handle g, F&& f) {
+    if (!g) return fail(FDTD_ERR_ARG, "null group");
+    for (size_t r = 0; r < g->member.size(); ++r)
+        if (int rc = f(g->member[r])) return rc;
+    return FDTD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fdtd3d_group_create(const fdtd3d_desc* desc, int n_slabs, const int* devices, fdtd3d_group_handle* out) {
+    if (!out) return fail(FDTD_ERR_ARG, "null output handle");
+    *out = nullptr;
+    if (!desc) return fail(FDTD_ERR_ARG, "null descriptor");
+    if (desc->struct_size != (int32_t)sizeof(fdtd3d_desc)) return fail(FDTD_ERR_ARG, "descriptor size %d, library expects %zu", desc->struct_size, sizeof(fdtd3d_desc));
+    if (n_slabs < 1 || n_slabs > desc->Nz) return fail(FDTD_ERR_ARG, "cannot split %d layers into %d slabs", desc->Nz, n_slabs);
+    if (desc->z_lo != 0 || desc->z_hi != desc->Nz) return fail(FDTD_ERR_ARG, "group: the descriptor must describe the whole grid (z_lo = 0, z_hi = Nz)");
+    try {
+        auto g = std::make_unique<fdtd3d_group>();
+        if (int rc = build_group(g.get(), desc, n_slabs, devices)) return rc;
+        *out = g.release();
+    } catch (const std::bad_alloc&) {
+        return fail(FDTD_ERR_HOST, "out of host memory");
+    }
+    return FDTD_OK;
+}
+
+int fdtd3d_group_destroy(fdtd3d_group_handle g) {
+    delete g;
+    return FDTD_OK;
+}
+
+int fdtd3d_group_slabs(fdtd3d_group_handle g) { return g ? (int)g->member.size() : 0; }
+
+fdtd3d_handle fdtd3d_group_member(fdtd3d_group_handle g, int r) {
+    return (g && r >= 0 && r < (int)g->member.size()) ? g->member[r] : nullptr;
+}
+
+int fdtd3d_group_step(fdtd3d_group_handle g, int n0, int count) {
+    if (!g) return fail(FDTD_ERR_ARG, "null group");
+    for (int n = n0; n < n0 + count; ++n) {
+        int rc;
+        if (g->member.size() == 1) {
+            DeviceScope scope(g->device[0]);
+            rc = fdtd3d_step(g->member[0], n, 1, g->run[0]);
+        } else {
+            rc = g->fused ? step_fused(g, n) : step_halves(g, n);
+        }
+        if (rc) return rc;
+    }
+    return FDTD_OK;
+}
+
+int fdtd3d_group_sync(fdtd3d_group_handle g) {
+    if (!g) return fail(FDTD_ERR_ARG, "null group");
+    for (size_t r = 0; r < g->member.size(); ++r) {
+        DeviceScope scope(g->device[r]);
+        FDTD_HIP(hipStreamSynchronize(g->run[r]));
+        FDTD_HIP(hipStreamSynchronize(g->up[r]));
+        FDTD_HIP(hipStreamSynchronize(g->down[r]));
+    }
+    return FDTD_OK;
+}
+
+// Whole-problem calls: every member takes (or reports) its own layers of the global host arrays.
+int fdtd3d_group_set_array(fdtd3d_group_handle g, int id, const double* host, size_t n) {
+    if (int rc = g ? fdtd3d_group_sync(g) : FDTD_OK) return rc;
+    return each_member(g, [&](fdtd3d_handle h) { return fdtd3d_set_array(h, id, host, n); });
+}
+int fdtd3d_group_get_array(fdtd3d_group_handle g, int id, double* host, size_t n) {
+    if (int rc = g ? fdtd3d_group_sync(g) : FDTD_OK) return rc;
+    return each_member(g, [&](fdtd3d_handle h) { return fdtd3d_get_array(h, id, host, n); });
+}
+int fdtd3d_group_fill_materials(fdtd3d_group_handle g, uint64_t seed, double elo, double ehi, double mlo, double mhi) {
+    return each_member(g, [&](fdtd3d_handle h) { return fdtd3d_fill_materials(h, seed, elo, ehi, mlo, mhi); });
+}
+int fdtd3d_group_fill_reference_materials(fdtd3d_group_handle g) {
+    return each_member(g, [&](fdtd3d_handle h) { return fdtd3d_fill_reference_materials(h); });
+}
+int fdtd3d_group_observe_accumulate(fdtd3d_group_handle g, double weight, int reset) {
+    if (!g) return fail(FDTD_ERR_ARG, "null group");
+    for (size_t r = 0; r < g->member.size(); ++r)
+        if (int rc = fdtd3d_observe_accumulate(g->member[r], weight, reset, g->run[r])) return rc;
+    return FDTD_OK;
+}
+int fdtd3d_group_observe_rms(fdtd3d_group_handle g, double* host, size_t n) {
+    return each_member(g, [&](fdtd3d_handle h) { return fdtd3d_observe_rms(h, host, n); });
+}
+int fdtd3d_group_observe_frame(fdtd3d_group_handle g, double* ex_center, double* e_mag, size_t n) {
+    if (!g) return fail(FDTD_ERR_ARG, "null group");
+    for (size_t r = 0; r < g->member.size(); ++r)
+        if (int rc = fdtd3d_observe_frame(g->member[r], ex_center, e_mag, n, g->run[r])) return rc;
+    return FDTD_OK;
+}
+
+}  // extern "C"

@@ -253,6 +253,116 @@ class Engine3D(_Common):
         return v.value
 
 
+class _Member(Engine3D):
+    """A slab of an EngineGroup3D: the group owns the handle."""
+
+    def __init__(self, handle, N, npml, precision, desc):
+        self.h, self.N, self.npml, self.precision, self.desc = handle, tuple(N), tuple(npml), precision, desc
+
+    def close(self) -> None:
+        self.h = None
+
+
+class EngineGroup3D:
+    """Several z-slabs of one problem, possibly on several GPUs, stepped from this one host thread
+    (fdtd3d_group_* in include/fdtd_engine.h).  Arrays are the same global host arrays an Engine3D takes."""
+
+    def __init__(self, N, npml, d, dt, mu0, k_Jx, n_wf, n_slabs, precision=32, has_mu=False, mode=MODE_FUSED, devices=None):
+        self.N, self.npml, self.precision = tuple(N), tuple(npml), precision
+        desc = Desc3D(C.sizeof(Desc3D), N[0], N[1], N[2], (C.c_int32 * 6)(*npml), k_Jx, n_wf, precision, int(has_mu),
+                      mode, 0, N[2], -1, d[0], d[1], d[2], dt, mu0)
+        self.desc = desc
+        self.h = C.c_void_p()
+        L = lib()
+        L.fdtd3d_group_member.restype = C.c_void_p
+        dev = (C.c_int * n_slabs)(*devices) if devices is not None else None
+        _check(L.fdtd3d_group_create(C.byref(desc), C.c_int(n_slabs), dev, C.byref(self.h)), "fdtd3d_group_create")
+        self.members = [_Member(C.c_void_p(L.fdtd3d_group_member(self.h, C.c_int(r))), N, npml, precision, desc)
+                        for r in range(L.fdtd3d_group_slabs(self.h))]
+
+    def size(self, id_: int) -> int:
+        return self.members[0].size(id_)
+
+    def set(self, id_: int, arr) -> None:
+        a = np.ascontiguousarray(arr, dtype=np.float64).ravel()
+        if id_ >= TAB:                      # tables, source plane and waveform are not split: every slab holds them
+            for m in self.members:
+                m.set(id_, a)
+            return
+        _check(lib().fdtd3d_group_set_array(self.h, C.c_int(id_), a.ctypes.data_as(_dp), C.c_size_t(a.size)), f"group_set_array({id_})")
+
+    def get(self, id_: int, shape=None) -> np.ndarray:
+        out = np.zeros(self.size(id_), dtype=np.float64)
+        _check(lib().fdtd3d_group_get_array(self.h, C.c_int(id_), out.ctypes.data_as(_dp), C.c_size_t(out.size)), f"group_get_array({id_})")
+        return out.reshape(shape) if shape is not None else out
+
+    def step(self, n0: int, count: int = 1) -> None:
+        _check(lib().fdtd3d_group_step(self.h, C.c_int(n0), C.c_int(count)), "fdtd3d_group_step")
+
+    def sync(self) -> None:
+        _check(lib().fdtd3d_group_sync(self.h), "fdtd3d_group_sync")
+
+    def fill_materials(self, seed, eps_lo, eps_hi, mu_lo, mu_hi) -> None:
+        _check(lib().fdtd3d_group_fill_materials(self.h, C.c_uint64(seed), C.c_double(eps_lo), C.c_double(eps_hi),
+                                                 C.c_double(mu_lo), C.c_double(mu_hi)), "fdtd3d_group_fill_materials")
+
+    def fill_reference_materials(self) -> None:
+        _check(lib().fdtd3d_group_fill_reference_materials(self.h), "fdtd3d_group_fill_reference_materials")
+
+    def observe_accumulate(self, weight: float, reset: bool) -> None:
+        _check(lib().fdtd3d_group_observe_accumulate(self.h, C.c_double(weight), C.c_int(int(reset))), "fdtd3d_group_observe_accumulate")
+
+    def observe_rms(self) -> np.ndarray:
+        out = np.zeros(self.N[0] * self.N[1] * self.N[2])
+        _check(lib().fdtd3d_group_observe_rms(self.h, out.ctypes.data_as(_dp), C.c_size_t(out.size)), "fdtd3d_group_observe_rms")
+        return out
+
+    def observe_frame(self):
+        n = self.N[0] * self.N[1] * self.N[2]
+        a, b = np.zeros(n), np.zeros(n)
+        _check(lib().fdtd3d_group_observe_frame(self.h, a.ctypes.data_as(_dp), b.ctypes.data_as(_dp), C.c_size_t(n)), "fdtd3d_group_observe_frame")
+        return a, b
+
+    def sumsq(self, id_: int) -> float:
+        self.sync()
+        return sum(m.sumsq(id_) for m in self.members)
+
+    def checksum(self, id_: int) -> int:
+        self.sync()
+        return sum(m.checksum(id_) for m in self.members) % 2 ** 64
+
+    def owner(self, k: int) -> "_Member":
+        """The member that owns cell layer k (the last one also plane Nz)."""
+        bounds = self.bounds()
+        for m, (lo, hi) in zip(self.members, bounds):
+            if lo <= k < hi or (hi == self.N[2] and k == hi):
+                return m
+        raise EngineError(f"no slab owns layer {k}")
+
+    def bounds(self):
+        R, Nz = len(self.members), self.N[2]
+        base, extra = divmod(Nz, R)
+        out, lo = [], 0
+        for r in range(R):
+            hi = lo + base + (1 if r < extra else 0)
+            out.append((lo, hi))
+            lo = hi
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            lib().fdtd3d_group_destroy(self.h)
+            self.h = None
+            for m in self.members:
+                m.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Engine2D(_Common):
     """Device-resident 2-D (Ey, Hx, Hz) state with Lorentz histories plus its two kernels."""
     _p = "fdtd2d_"

@@ -222,6 +222,34 @@ int fdtd3d_tune(fdtd3d_handle h, int chunk, int remap, int rows);
 int fdtd3d_kernel_timing(fdtd3d_handle h, int enable);
 int fdtd3d_kernel_time(fdtd3d_handle h, int kind, int* launches, double* total_ms);
 
+/* ---- Several slabs driven from one host thread ------------------------------------------
+ * FDTD3D::run() steps its whole grid from one thread (FDTD3D.cpp:1062-1111).  A group is that
+ * loop for a grid cut into `n_slabs` balanced z-slabs, slab r on device devices[r] (NULL: r modulo
+ * the visible device count): fdtd3d_group_step() launches every slab's kernels on streams of its
+ * own device, edge planes first, and copies the ghost planes device to device (peer copies over
+ * xGMI between different devices) while the bulk of each slab is computed.  `desc` describes the
+ * whole grid (z_lo = 0, z_hi = Nz; `device` is ignored); all three storage modes work.  Results
+ * equal those of one engine holding the whole grid, bit for bit.
+ * The set/get/fill/observe calls below address the whole problem with the same global host arrays
+ * as the single-engine calls; fdtd3d_group_member() hands out a slab's own handle for anything
+ * else (CPML tables and the source go to every member; probes to the member that owns the cell).
+ * Calls return once the work is queued; fdtd3d_group_sync() waits for it (downloads do so
+ * themselves). */
+typedef struct fdtd3d_group* fdtd3d_group_handle;
+int fdtd3d_group_create(const fdtd3d_desc* desc, int n_slabs, const int* devices, fdtd3d_group_handle* out);
+int fdtd3d_group_destroy(fdtd3d_group_handle g);
+int fdtd3d_group_slabs(fdtd3d_group_handle g);
+fdtd3d_handle fdtd3d_group_member(fdtd3d_group_handle g, int r);
+int fdtd3d_group_step(fdtd3d_group_handle g, int n0, int count);
+int fdtd3d_group_sync(fdtd3d_group_handle g);
+int fdtd3d_group_set_array(fdtd3d_group_handle g, int id, const double* host, size_t n);
+int fdtd3d_group_get_array(fdtd3d_group_handle g, int id, double* host, size_t n);
+int fdtd3d_group_fill_materials(fdtd3d_group_handle g, uint64_t seed, double eps_lo, double eps_hi, double mu_lo, double mu_hi);
+int fdtd3d_group_fill_reference_materials(fdtd3d_group_handle g);
+int fdtd3d_group_observe_accumulate(fdtd3d_group_handle g, double weight, int reset);
+int fdtd3d_group_observe_rms(fdtd3d_group_handle g, double* host, size_t n);
+int fdtd3d_group_observe_frame(fdtd3d_group_handle g, double* ex_center, double* e_mag, size_t n);
+
 /* ------------------------------------------------------------------ 2-D -- */
 
 /* Array ids, 2-D.  Shapes (canonical order, k fastest), FDTD2D.h:33-38:

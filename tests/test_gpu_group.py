@@ -1,0 +1,128 @@
+"""Slab groups (fdtd3d_group_*): several z-slabs of one problem stepped from one host thread, ghost
+planes copied device to device on streams.  On a one-GPU box all slabs sit on device 0; the
+choreography, the events and the copies are the same ones a multi-GPU node runs (there the copies
+are peer copies).  Every result must equal the whole-grid result bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import fdtd_amd
+from fdtd_amd import engine as E
+from oracle import pyoracle as po
+from tests import util
+from tests.test_gpu_parity import FIX3D
+
+pytestmark = pytest.mark.gpu
+
+
+def group_from_meta(meta, prec, n_slabs, mode, **kw):
+    return E.EngineGroup3D(meta["N"], meta["npml"], (meta["dx"], meta["dy"], meta["dz"]), meta["dt"], meta["mu0"],
+                           meta["k_Jx"], meta["steps"], n_slabs, precision=prec, mode=mode, **kw)
+
+
+@pytest.mark.parametrize("name", FIX3D)
+@pytest.mark.parametrize("mode", [E.MODE_FULL, E.MODE_LEAN, E.MODE_FUSED])
+@pytest.mark.parametrize("n_slabs", [2, 3])
+def test_group_fp64_equals_reference_golden(name, mode, n_slabs):
+    meta, ins, outs, _ = util.load_fixture(name)
+    g = group_from_meta(meta, 64, n_slabs, mode)
+    util.feed(g, ins)
+    got = util.run_snapshots(g, meta, outs)
+    for key, want in outs.items():
+        util.assert_equal_arrays(got[key], want, f"{name} group x{n_slabs} mode {mode} step {key[0]} array {key[1]}")
+    g.close()
+
+
+@pytest.mark.parametrize("mode", [E.MODE_LEAN, E.MODE_FUSED])
+def test_group_fp32_equals_twin_and_single_engine(mode):
+    meta, ins, outs, _ = util.load_fixture("g3_3d_hetero")
+    g = group_from_meta(meta, 32, 4, mode)
+    tw = util.twin3d_from_meta(meta, 32)
+    util.feed(g, ins)
+    util.feed(tw, ins)
+    got = util.run_snapshots(g, meta, outs)
+    ref = util.run_snapshots(tw, meta, outs)
+    for key in outs:
+        util.assert_equal_arrays(got[key], ref[key], f"group fp32 mode {mode} step {key[0]} array {key[1]}")
+    one = fdtd_amd.Engine3D(meta["N"], meta["npml"], (meta["dx"], meta["dy"], meta["dz"]), meta["dt"], meta["mu0"], meta["k_Jx"],
+                            meta["steps"], precision=32, mode=mode)
+    util.feed(one, ins)
+    one.step(0, max(meta["snapshots"]))
+    for id_ in (E.DX, E.DY, E.BZ):
+        assert g.checksum(id_) == one.checksum(id_)
+        assert g.sumsq(id_) == pytest.approx(one.sumsq(id_), rel=1e-12)
+
+
+def test_group_observables_and_probe():
+    meta, ins, outs, extra = util.load_fixture("g2_3d_cavity")
+    g = group_from_meta(meta, 64, 3, E.MODE_FUSED)
+    tw = util.twin3d_from_meta(meta, 64)
+    util.feed(g, ins)
+    util.feed(tw, ins)
+    pi, pj, pk = meta["probe_cell"]
+    g.owner(pk).probe_add(E.EX, pi, pj, pk)
+    for n in range(25):
+        g.step(n, 1)
+        tw.step(n, 1)
+        g.observe_accumulate(0.1, n % 10 == 0)
+        tw.observe_accumulate(0.1, n % 10 == 0)
+    util.assert_equal_arrays(g.observe_rms(), tw.observe_rms(), "group RMS window")
+    a, b = g.observe_frame()
+    ta, tb = tw.observe_frame()
+    util.assert_equal_arrays(a, ta, "group centred Ex")
+    util.assert_equal_arrays(b, tb, "group |E|")
+    util.assert_equal_arrays(g.owner(pk).probe_read()[:, 0], extra["probe"][:25], "group probe series")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_group_random_configurations_equal_twin(seed):
+    from tests.test_gpu_fused import _random_case
+    rng = np.random.default_rng(4000 + seed)
+    N, npml, prec, has_mu, rows, chunk = _random_case(rng)
+    N = (N[0], N[1], max(N[2], 8))
+    n_slabs = int(rng.integers(1, min(6, N[2]) + 1))
+    mode = int(rng.choice([E.MODE_FULL, E.MODE_LEAN, E.MODE_FUSED]))
+    K = po.consts()
+    d = (5e-8, 6e-8, 7e-8)
+    dt = 5e-8 / (2 * K["c0"])
+    steps = 11
+    kJ = int(rng.integers(0, N[2] + 1))
+    g = E.EngineGroup3D(N, npml, d, dt, K["mu0"], kJ, steps, n_slabs, precision=prec, has_mu=has_mu, mode=mode)
+    for m in g.members:
+        m.tune(chunk, 1, rows if mode == E.MODE_FUSED else 1 + rows % 4)
+    tw = po.Twin3D(prec, N, npml, d, dt, K["mu0"], kJ, steps, has_mu)
+    wf = rng.standard_normal(steps)
+    mag = rng.random((N[0], N[1] + 1))
+    for be in (g, tw):
+        for a in range(3):
+            for s in range(2):
+                if npml[a * 2 + s]:
+                    tabs = po.cpml_face(npml[a * 2 + s], s, d[a], d[a], dt)
+                    for k in range(6):
+                        be.set(po.tab_id(a, s, k), tabs[k])
+        be.set(po.JX_WF, wf)
+        be.set(po.JX_MAG, mag)
+        be.fill_materials(seed, K["eps0"], 4 * K["eps0"], K["mu0"], 3 * K["mu0"])
+    g.step(0, 4)
+    g.step(4, steps - 4)
+    tw.step(0, steps)
+    for id_ in po.FIELDS3D + po.ALL_PHI3D:
+        if g.size(id_):
+            util.assert_equal_arrays(g.get(id_), tw.get(id_), f"seed {seed}: group N={N} npml={npml} x{n_slabs} mode {mode} fp{prec} mu={has_mu}, array {id_}")
+    g.close()
+
+
+def test_group_refusals():
+    meta, _, _, _ = util.load_fixture("g1_3d_cpml")
+    with pytest.raises(E.EngineError, match="cannot split"):
+        group_from_meta(meta, 32, meta["N"][2] + 1, E.MODE_FUSED)
+    with pytest.raises(E.EngineError, match="cannot split"):
+        group_from_meta(meta, 32, 0, E.MODE_FUSED)
+    with pytest.raises(E.EngineError, match="device"):
+        group_from_meta(meta, 32, 2, E.MODE_FUSED, devices=[0, 4096])
+    L = E.lib()
+    desc = E.Desc3D(C.sizeof(E.Desc3D), 24, 20, 28, (C.c_int32 * 6)(4, 4, 4, 4, 4, 4), 6, 8, 32, 0, 2, 3, 28, -1, 5e-8, 5e-8, 5e-8, 8e-17, 4e-7 * np.pi)
+    h = C.c_void_p()
+    assert L.fdtd3d_group_create(C.byref(desc), 2, None, C.byref(h)) == 1 and b"whole grid" in L.fdtd_last_error()
+    assert L.fdtd3d_group_step(None, 0, 1) == 1 and L.fdtd3d_group_slabs(None) == 0 and L.fdtd3d_group_destroy(None) == 0
