@@ -9,7 +9,7 @@
 #include <string>
 #include <vector>
 
-struct fdtd3d_engine;
+struct fdtd3d_group;
 class FieldWriter3D;
 
 struct Sim3DConfig {
@@ -20,6 +20,7 @@ struct Sim3DConfig {
     int precision;         // 64 reproduces the reference's files byte for byte; 32 is the fast path
     bool lean;             // keep only D and B on the device
     bool fused;            // one kernel per time step (implies lean storage, two buffer sets)
+    int slabs;             // z-slabs, slab r on GPU r modulo the visible count; 0 = one per visible GPU
     int n_T0;              // steps per optical period: RMS window = n_T0/2, weights 4/n_T0
     int frame_every;
     bool write_files;
@@ -27,7 +28,7 @@ struct Sim3DConfig {
     std::string out_dir;
     // The reference's hard-coded problem (FDTD3D.cpp:21-39, :71, FDTD3D.h:54-56).
     static Sim3DConfig reference_default();
-    // Overrides from FDTD3D_NX / _NY / _NZ / _STEPS / _NPML / _KJX / _PRECISION / _LEAN / _FUSED / _FRAME_EVERY / _BINARY_VTI /
+    // Overrides from FDTD3D_NX / _NY / _NZ / _STEPS / _NPML / _KJX / _PRECISION / _LEAN / _FUSED / _SLABS / _FRAME_EVERY / _BINARY_VTI /
     // _WRITE / _OUT environment variables (the reference's main() takes no arguments).
     void apply_environment();
 };
@@ -50,7 +51,7 @@ private:
     void dump_frame(int step);
 
     Sim3DConfig m_cfg;
-    fdtd3d_engine* m_engine = nullptr;
+    fdtd3d_group* m_group = nullptr;   // the slabs of the grid (a single one by default)
     std::unique_ptr<FieldWriter3D> m_out;
     std::vector<double> m_a, m_b;     // download buffers, [Nz][Ny][Nx]
     double m_step_seconds = 0.0;

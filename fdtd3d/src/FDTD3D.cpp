@@ -2,6 +2,7 @@
 // fdtd_engine.h, output cadence of the reference's run() (fdtd3d/src/FDTD3D.cpp:1062-1111).
 #include "FDTD3D.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -43,6 +44,7 @@ Sim3DConfig Sim3DConfig::reference_default() {
     c.precision = 64;
     c.lean = true;
     c.fused = true;
+    c.slabs = 1;
     c.binary_vti = false;
     c.n_T0 = static_cast<int>(std::round(2 * cells_per_wavelength));
     c.frame_every = 20;
@@ -59,6 +61,7 @@ void Sim3DConfig::apply_environment() {
     if (env_int("FDTD3D_NPML", v)) for (int& n : n_pml) n = v;
     if (env_int("FDTD3D_LEAN", v)) lean = v != 0;
     if (env_int("FDTD3D_FUSED", v)) fused = v != 0;
+    env_int("FDTD3D_SLABS", slabs);
     if (env_int("FDTD3D_WRITE", v)) write_files = v != 0;
     if (env_int("FDTD3D_BINARY_VTI", v)) binary_vti = v != 0;
     if (const char* e = std::getenv("FDTD3D_OUT")) if (*e) out_dir = e;
@@ -70,7 +73,7 @@ FDTD3D::FDTD3D() : m_cfg(Sim3DConfig::reference_default()) {
 }
 FDTD3D::FDTD3D(const Sim3DConfig& cfg) : m_cfg(cfg) { build(); }
 
-FDTD3D::~FDTD3D() { fdtd3d_destroy(m_engine); }
+FDTD3D::~FDTD3D() { fdtd3d_group_destroy(m_group); }
 
 void FDTD3D::build() {
     const Sim3DConfig& c = m_cfg;
@@ -87,17 +90,23 @@ void FDTD3D::build() {
     d.mode = c.fused ? FDTD3D_MODE_FUSED : (c.lean ? FDTD3D_MODE_LEAN : FDTD3D_MODE_FULL);
     d.z_lo = 0; d.z_hi = c.Nz; d.device = -1;
     d.dx = c.dx; d.dy = c.dy; d.dz = c.dz; d.dt = c.dt; d.mu0 = mu0;
-    must(fdtd3d_create(&d, &m_engine), "fdtd3d_create");
+    int slabs = c.slabs > 0 ? c.slabs : fdtd_device_count();
+    if (slabs < 1) slabs = 1;
+    if (slabs > c.Nz) slabs = c.Nz;
+    must(fdtd3d_group_create(&d, slabs, nullptr, &m_group), "fdtd3d_group_create");
+    if (slabs > 1) std::cout << "[grid] " << slabs << " z-slabs on " << std::min(slabs, std::max(fdtd_device_count(), 1)) << " GPU(s)\n";
 
     // source, materials, CPML: generated on the host once, handed over, then dropped
     {
         std::vector<double> wf(c.steps), mag(static_cast<size_t>(c.Nx) * (c.Ny + 1));
         must(fdtd3d_default_source(c.Nx, c.Ny, c.steps, c.dx, c.dy, c.dz, c.dt, wf.data(), mag.data()), "default source");
-        must(fdtd3d_set_array(m_engine, FDTD3D_JX_WF, wf.data(), wf.size()), "upload waveform");
-        must(fdtd3d_set_array(m_engine, FDTD3D_JX_MAG, mag.data(), mag.size()), "upload source magnitude");
+        for (int r = 0; r < slabs; ++r) {          // source and CPML tables are not split: every slab holds them
+            must(fdtd3d_set_array(fdtd3d_group_member(m_group, r), FDTD3D_JX_WF, wf.data(), wf.size()), "upload waveform");
+            must(fdtd3d_set_array(fdtd3d_group_member(m_group, r), FDTD3D_JX_MAG, mag.data(), mag.size()), "upload source magnitude");
+        }
     }
     // setupMaterials (reference FDTD3D.cpp:106-200) runs on the device: same fp64 arithmetic, no O(N^3) host loop
-    must(fdtd3d_fill_reference_materials(m_engine), "reference materials");
+    must(fdtd3d_group_fill_reference_materials(m_group), "reference materials");
     const double h[3] = {c.dx, c.dy, c.dz};
     for (int axis = 0; axis < 3; ++axis) for (int side = 0; side < 2; ++side) {
         const int n = c.n_pml[axis * 2 + side];
@@ -105,7 +114,8 @@ void FDTD3D::build() {
         std::vector<double> t(static_cast<size_t>(6) * n);
         must(fdtd_cpml_tables(n, side, h[axis], h[axis], c.dt, t.data()), "CPML tables");
         for (int kind = 0; kind < 6; ++kind)
-            must(fdtd3d_set_array(m_engine, FDTD3D_TAB + (axis * 2 + side) * 6 + kind, t.data() + static_cast<size_t>(kind) * n, n), "upload CPML table");
+            for (int r = 0; r < slabs; ++r)
+                must(fdtd3d_set_array(fdtd3d_group_member(m_group, r), FDTD3D_TAB + (axis * 2 + side) * 6 + kind, t.data() + static_cast<size_t>(kind) * n, n), "upload CPML table");
     }
     if (c.write_files) m_out = std::make_unique<FieldWriter3D>(c.out_dir, c.binary_vti ? FieldWriter3D::Encoding::appended : FieldWriter3D::Encoding::ascii);
     const size_t cells = static_cast<size_t>(c.Nx) * c.Ny * c.Nz;
@@ -115,7 +125,7 @@ void FDTD3D::build() {
 
 void FDTD3D::dump_frame(int step) {
     const Sim3DConfig& c = m_cfg;
-    must(fdtd3d_observe_frame(m_engine, m_a.data(), m_b.data(), m_a.size(), nullptr), "observe frame");
+    must(fdtd3d_group_observe_frame(m_group, m_a.data(), m_b.data(), m_a.size()), "observe frame");
     if (!m_out) return;
     m_out->write_vti("Ex", m_a, c.Nx, c.Ny, c.Nz, c.dx, c.dy, c.dz, step);
     m_out->write_vti("E_mag", m_b, c.Nx, c.Ny, c.Nz, c.dx, c.dy, c.dz, step);
@@ -127,10 +137,10 @@ void FDTD3D::run() {
     const double weight = 4.0 / c.n_T0;
     for (int n = 0; n < c.steps; ++n) {
         const auto t0 = std::chrono::steady_clock::now();
-        must(fdtd3d_step(m_engine, n, 1, nullptr), "step");
-        must(fdtd3d_observe_accumulate(m_engine, weight, n % half_period == 0, nullptr), "RMS window");
+        must(fdtd3d_group_step(m_group, n, 1), "step");
+        must(fdtd3d_group_observe_accumulate(m_group, weight, n % half_period == 0), "RMS window");
         if ((n + 1) % half_period == 0) {
-            must(fdtd3d_observe_rms(m_engine, m_a.data(), m_a.size()), "RMS download");
+            must(fdtd3d_group_observe_rms(m_group, m_a.data(), m_a.size()), "RMS download");
             if (m_out) m_out->write_vti("E_mag_rms", m_a, c.Nx, c.Ny, c.Nz, c.dx, c.dy, c.dz, n + 1);
         }
         if (n % c.frame_every == 0) {

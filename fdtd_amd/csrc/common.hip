@@ -62,3 +62,8 @@ void KernelTimer::release() {
 
 extern "C" const char* fdtd_last_error(void) { return fdtd::last_error_slot().c_str(); }
 extern "C" const char* fdtd_engine_version(void) { return "fdtd_engine gfx950 0.1 (wave64, 16-byte lanes, fp-contract off)"; }
+extern "C" int fdtd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}

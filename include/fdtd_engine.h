@@ -39,6 +39,8 @@ extern "C" {
 const char* fdtd_last_error(void);
 /* Library build identification ("fdtd_engine gfx950 ..."). */
 const char* fdtd_engine_version(void);
+/* Number of HIP devices this process can use (0 if there is none). */
+int fdtd_device_count(void);
 
 /* ------------------------------------------------------------------ 3-D -- */
 

@@ -146,6 +146,30 @@ def test_fused_slabs_equal_whole_grid_384():
     assert got == want
 
 
+@pytest.mark.parametrize("mode", [E.MODE_FUSED, E.MODE_LEAN])
+def test_slab_group_equals_whole_grid_512(mode):
+    """A slab group (one host thread, streams, device-to-device ghost copies running beside the kernels)
+    of 3 uneven slabs == one engine on the whole 512 x 512 x 640 grid, eps/mu grids and 20-layer CPML."""
+    N, steps = (512, 512, 640), 15
+    whole = make(N, (20,) * 6, E.MODE_LEAN, True, steps=steps)
+    whole.step(0, steps)
+    want = [whole.checksum(i) for i in FIELDS]
+    whole.close()
+    K = fs.constants()
+    d = (1053e-9 / 20,) * 3
+    dt = d[0] / (2 * K["c0"])
+    g = E.EngineGroup3D(N, (20,) * 6, d, dt, K["mu0"], 20, steps, 3, precision=32, has_mu=True, mode=mode)
+    wf, mag = fs.default_source3d(N[0], N[1], steps, d, dt)
+    for m in g.members:
+        fs.load_cpml3d(m, d, dt)
+        m.set(E.JX_WF, wf)
+        m.set(E.JX_MAG, mag)
+    g.fill_materials(1234, K["eps0"], 4 * K["eps0"], K["mu0"], 2 * K["mu0"])
+    g.step(0, steps)
+    assert [g.checksum(i) for i in FIELDS] == want
+    g.close()
+
+
 def test_whole_memory_grid_equals_three_slabs():
     """1024 x 1024 x 3072 cells on one GPU (242 GB with the fused kernel's two buffer sets; every array
     holds 3.2e9 elements, beyond 32-bit indexing) against the same problem as three 1024-layer slabs, whose

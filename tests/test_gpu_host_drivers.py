@@ -67,6 +67,24 @@ def test_fdtd3d_driver_full_storage_and_fp32(tmp_path):
         assert util.rel_l2(got, want) < 1e-6
 
 
+def test_fdtd3d_driver_on_slabs_writes_the_reference_files(tmp_path):
+    """FDTD3D_SLABS: the grid cut into z-slabs driven from the driver's one host thread (one per GPU on a
+    multi-GPU node; all on the one device here) -- same files, byte for byte, in every storage mode."""
+    fx = os.path.join(util.GOLDEN, "run3d")
+    meta = json.load(open(os.path.join(fx, "meta.json")))
+    env = dict(FDTD3D_NX=meta["N"][0], FDTD3D_NY=meta["N"][1], FDTD3D_NZ=meta["N"][2], FDTD3D_NPML=meta["npml"][0],
+               FDTD3D_STEPS=meta["steps"], FDTD3D_PRECISION=64)
+    out = _run("fdtd3d", dict(env, FDTD3D_SLABS=3), str(tmp_path))
+    assert "3 z-slabs" in out
+    _compare_dir(str(tmp_path / "output_3d"), fx)
+    _run("fdtd3d", dict(env, FDTD3D_SLABS=5, FDTD3D_FUSED=0, FDTD3D_LEAN=1), str(tmp_path))
+    _compare_dir(str(tmp_path / "output_3d"), fx)
+    _run("fdtd3d", dict(env, FDTD3D_SLABS=2, FDTD3D_FUSED=0, FDTD3D_LEAN=0), str(tmp_path))
+    _compare_dir(str(tmp_path / "output_3d"), fx)
+    _run("fdtd3d", dict(env, FDTD3D_SLABS=0), str(tmp_path))             # one slab per visible GPU
+    _compare_dir(str(tmp_path / "output_3d"), fx)
+
+
 def test_fdtd3d_driver_binary_vti(tmp_path):
     """Opt-in raw appended VTI: the Float32 payload equals the reference's ASCII values rounded to fp32."""
     fx = os.path.join(util.GOLDEN, "run3d")
