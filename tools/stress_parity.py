@@ -3,12 +3,13 @@ over a range of further seeds:  python tools/stress_parity.py LO HI   (needs the
 import sys, time, traceback
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests import test_gpu_fused as tf, test_gpu_fused2d as t2, test_gpu_parity as tp
+from tests import test_gpu_fused as tf, test_gpu_fused2d as t2, test_gpu_parity as tp, test_gpu_group as tg
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 t0 = time.time()
 for seed in range(lo, hi):
-    for name, fn in (("fused3d", tf.test_fused_random_configurations_equal_twin), ("slabs3d", tf.test_fused_random_slab_partitions_equal_twin)):
+    for name, fn in (("fused3d", tf.test_fused_random_configurations_equal_twin), ("slabs3d", tf.test_fused_random_slab_partitions_equal_twin),
+                     ("group3d", tg.test_group_random_configurations_equal_twin)):
         try:
             fn(seed)
         except Exception as e:
