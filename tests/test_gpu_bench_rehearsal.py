@@ -44,6 +44,26 @@ def test_two_and_three_ranks_equal_one(mode):
             assert key in many
 
 
+@pytest.mark.parametrize("mode", ["fused", "full"])
+def test_single_process_group_mode_equals_one(mode):
+    """`bench.py --gpus N` started as a plain process: one host thread drives N slabs through a slab group
+    (here all on cuda:0).  Same grid, same checksum, same JSON keys."""
+    one = _bench({"FDTD_BENCH_MODE": mode}, 1)
+    env = dict(os.environ, FDTD_BENCH_N="192", FDTD_BENCH_NZ="384", FDTD_BENCH_ONE_DEVICE="1", FDTD_BENCH_MODE=mode)
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(key, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "3", "--steps", "7", "--warmup", "2"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    many = json.loads(lines[0])
+    assert many["n_gpus"] == 3 and many["config"]["grid"] == one["config"]["grid"] and "one process" in many["config"]["decomposition"]
+    assert many["checks"]["checksum_dx"] == one["checks"]["checksum_dx"]
+    for key in ("metric", "value", "unit", "ms_per_step", "roofline", "scaling", "dtype", "config"):
+        assert key in many
+
+
 def test_rccl_self_exchange_on_engine_memory():
     """What one GPU can show of the RCCL path itself: the backend takes the tensors that alias the
     engine's ghost planes, and batch_isend_irecv orders correctly against the kernels on the compute
