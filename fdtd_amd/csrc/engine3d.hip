@@ -247,9 +247,11 @@ struct Engine3 : fdtd3d_engine {
     size_t arena_cap = 0, arena_used = 0;
     bool planning = false;
     static constexpr size_t kGranule = 4096;
+    size_t gap_bytes = 0;
     int dalloc(void** p, size_t nbytes, int fill_byte_pattern_zero = 1) {
         if (nbytes == 0) { *p = nullptr; return FDTD_OK; }
-        const size_t span = (nbytes + kGranule - 1) / kGranule * kGranule;
+        size_t span = (nbytes + kGranule - 1) / kGranule * kGranule;
+        if (nbytes >= ((size_t)256 << 20)) span += gap_bytes;      // experiment: spread the big arrays
         if (planning) { arena_used += span; *p = nullptr; return FDTD_OK; }
         if (arena && arena_used + span <= arena_cap) {
             *p = arena + arena_used;
@@ -345,6 +347,7 @@ struct Engine3 : fdtd3d_engine {
         if (const char* e = getenv("FDTD_ROWS_PER_GROUP")) { int w = atoi(e); if (w >= 1 && w <= 4) wpb = w; }
 
         int rc;
+        if (const char* e = getenv("FDTD_ARENA_GAP_KB")) gap_bytes = (size_t)atoll(e) << 10;
         planning = true; arena_used = 0;
         if ((rc = allocate_all())) return rc;
         planning = false;
