@@ -74,6 +74,55 @@ __global__ void k_fill_sphere(T* arr, CompGeom g, int c, int N0, int N1, int N2,
     }
 }
 
+// Array exchange for field-shaped arrays: the host order is [i][j][k] with k unit-stride, the device
+// order [plane][row][column] with i unit-stride.  One workgroup transposes a 32 (k) x 32 (i) tile of
+// row j through LDS so that both sides are accessed in their unit-stride direction.  `stage` holds
+// the host's values for columns [i0, i0+ci), all j, all k.  Wall columns (i >= Nx) and planes the
+// slab does not store are skipped.
+struct ExchangeGeom {
+    int n1, n2;        // canonical extents along j and k
+    int i0, ci;        // chunk of columns in the staging buffer
+    int Nx, px, ny1, nzp, zoff;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) k_scatter_field(const double* __restrict__ stage, T* __restrict__ dev, ExchangeGeom g) {
+    __shared__ T tile[32][33];
+    const int j = blockIdx.y, k0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int il = ty; il < 32; il += 8) {
+        const int k = k0 + tx;
+        if (il < g.ci && k < g.n2) tile[il][tx] = (T)stage[((size_t)il * g.n1 + j) * g.n2 + k];
+    }
+    __syncthreads();
+    for (int kk = ty; kk < 32; kk += 8) {
+        const int k = k0 + kk, kl = k - g.zoff, i = g.i0 + tx;
+        if (tx < g.ci && k < g.n2 && kl >= 0 && kl < g.nzp && i < g.Nx) dev[((size_t)kl * g.ny1 + j) * g.px + i] = tile[tx][kk];
+    }
+}
+// The other direction; `den` (or the scalar `sdiv` when den is null and sdiv != 0) divides on the way
+// out, which is how E = D/eps and H = B/mu are reported from lean storage.  Positions the slab does
+// not store come back as 0 and are not copied to the caller by the host side.
+template <typename T>
+__global__ void __launch_bounds__(256) k_gather_field(double* __restrict__ stage, const T* __restrict__ dev, const T* __restrict__ den, T sdiv, ExchangeGeom g) {
+    __shared__ T tile[32][33];
+    const int j = blockIdx.y, k0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int kk = ty; kk < 32; kk += 8) {
+        const int k = k0 + kk, kl = k - g.zoff, i = g.i0 + tx;
+        T v = (T)0;
+        if (tx < g.ci && k < g.n2 && kl >= 0 && kl < g.nzp && i < g.Nx) {
+            const size_t off = ((size_t)kl * g.ny1 + j) * g.px + i;
+            v = dev[off];
+            if (den) v = v / den[off];
+            else if (sdiv != (T)0) v = v / sdiv;
+        }
+        tile[tx][kk] = v;
+    }
+    __syncthreads();
+    for (int il = ty; il < 32; il += 8) {
+        const int k = k0 + tx;
+        if (il < g.ci && k < g.n2) stage[((size_t)il * g.n1 + j) * g.n2 + k] = (double)tile[il][tx];
+    }
+}
+
 template <typename T>
 __global__ void k_fill_const(T* arr, size_t n, T v) {
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) arr[t] = v;
@@ -205,6 +254,7 @@ struct Engine3 : fdtd3d_engine {
 
     ~Engine3() override {
         for (void* p : allocs) (void)hipFree(p);
+        if (stage_d) (void)hipFree(stage_d);
         probes.release();
         timer.release();
     }
@@ -513,6 +563,73 @@ struct Engine3 : fdtd3d_engine {
         return FDTD_OK;
     }
 
+    // ---- field arrays cross through a device-side transpose, 32 columns of the host array at a time ----
+    double* stage_d = nullptr;
+    size_t stage_cap = 0;
+    int stage_reserve(size_t nbytes) {
+        if (nbytes <= stage_cap) return FDTD_OK;
+        if (stage_d) (void)hipFree(stage_d);
+        stage_d = nullptr; stage_cap = 0;
+        FDTD_HIP(hipMalloc((void**)&stage_d, nbytes));
+        stage_cap = nbytes;
+        return FDTD_OK;
+    }
+    void stage_trim() {          // a big staging buffer is only kept for the duration of one call
+        if (stage_cap > ((size_t)64 << 20)) { (void)hipFree(stage_d); stage_d = nullptr; stage_cap = 0; }
+    }
+    ExchangeGeom exchange_geom(const Map& m, int i0, int ci) const {
+        ExchangeGeom g;
+        g.n1 = m.n[1]; g.n2 = m.n[2]; g.i0 = i0; g.ci = ci;
+        g.Nx = d.Nx; g.px = px; g.ny1 = ny1; g.nzp = nzp; g.zoff = zoff;
+        return g;
+    }
+    int set_field(const Map& m, const double* host) {
+        const size_t per_i = (size_t)m.n[1] * m.n[2];
+        if (int rc = stage_reserve(std::min<size_t>(32, m.n[0]) * per_i * sizeof(double))) return rc;
+        const dim3 grid((m.n[2] + 31) / 32, m.n[1]);
+        for (int i0 = 0; i0 < m.n[0] && i0 < d.Nx; i0 += 32) {
+            const int ci = std::min(32, m.n[0] - i0);
+            FDTD_HIP(hipMemcpy(stage_d, host + (size_t)i0 * per_i, (size_t)ci * per_i * sizeof(double), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_scatter_field<T>, grid, dim3(256), 0, 0, stage_d, m.dev, exchange_geom(m, i0, ci));
+            if (m.dev2) hipLaunchKernelGGL(k_scatter_field<T>, grid, dim3(256), 0, 0, stage_d, m.dev2, exchange_geom(m, i0, ci));
+            FDTD_HIP(hipGetLastError());
+        }
+        FDTD_HIP(hipDeviceSynchronize());
+        stage_trim();
+        return FDTD_OK;
+    }
+    int get_field(const Map& m, const T* num, const T* den, T sdiv, double* host) {
+        const size_t per_i = (size_t)m.n[1] * m.n[2];
+        // layers this slab reports: its own, plus the closing plane k = Nz on the last slab
+        const int k_lo = d.z_lo, k_hi = std::min(m.n[2], last_rank ? d.Nz + 1 : d.z_hi);
+        if (int rc = stage_reserve(std::min<size_t>(32, m.n[0]) * per_i * sizeof(double))) return rc;
+        std::vector<double> buf;
+        const bool whole = k_lo == 0 && k_hi == m.n[2];
+        if (!whole) buf.resize(std::min<size_t>(32, m.n[0]) * per_i);
+        const dim3 grid((m.n[2] + 31) / 32, m.n[1]);
+        for (int i0 = 0; i0 < m.n[0]; i0 += 32) {
+            const int ci = std::min(32, m.n[0] - i0);
+            double* dst = host + (size_t)i0 * per_i;
+            if (i0 >= d.Nx) {               // the unstored wall column reads as zero
+                for (size_t q = 0; q < (size_t)ci * per_i; ++q) dst[q] = 0.0;
+                continue;
+            }
+            hipLaunchKernelGGL(k_gather_field<T>, grid, dim3(256), 0, 0, stage_d, num, den, sdiv, exchange_geom(m, i0, ci));
+            FDTD_HIP(hipGetLastError());
+            if (whole) {
+                FDTD_HIP(hipMemcpy(dst, stage_d, (size_t)ci * per_i * sizeof(double), hipMemcpyDeviceToHost));
+            } else {
+                FDTD_HIP(hipMemcpy(buf.data(), stage_d, (size_t)ci * per_i * sizeof(double), hipMemcpyDeviceToHost));
+                for (size_t row = 0; row < (size_t)ci * m.n[1]; ++row)
+                    if (k_hi > k_lo) std::memcpy(dst + row * m.n[2] + k_lo, buf.data() + row * m.n[2] + k_lo, (size_t)(k_hi - k_lo) * sizeof(double));
+            }
+            for (int i = std::max(i0, d.Nx); i < i0 + ci; ++i)      // wall column inside a mixed chunk
+                for (size_t q = 0; q < per_i; ++q) host[(size_t)i * per_i + q] = 0.0;
+        }
+        stage_trim();
+        return FDTD_OK;
+    }
+
     int set_array(int id, const double* host, size_t n) override {
         if (n != array_size(id) || (n && !host)) return fail(FDTD_ERR_ARG, "set_array(%d): expected %zu values, got %zu", id, array_size(id), n);
         if (id >= FDTD3D_TAB && id < FDTD3D_TAB + 36) {
@@ -525,6 +642,7 @@ struct Engine3 : fdtd3d_engine {
         if (!make_map(id, m)) return fail(FDTD_ERR_ARG, "set_array: unknown array id %d", id);
         if (n == 0) return FDTD_OK;
         if (!m.dev) return fail(FDTD_ERR_STATE, "set_array(%d): array is not resident in this storage mode", id);
+        if (m.kind == 0) return set_field(m, host);
         std::vector<T> st(m.dev_elems);
         FDTD_HIP(hipMemcpy(st.data(), m.dev, st.size() * sizeof(T), hipMemcpyDeviceToHost));
         size_t o = 0;
@@ -549,24 +667,20 @@ struct Engine3 : fdtd3d_engine {
         if (!make_map(id, m)) return fail(FDTD_ERR_ARG, "get_array: unknown array id %d", id);
         if (n == 0) return FDTD_OK;
         FDTD_HIP(hipDeviceSynchronize());
-        std::vector<T> st(m.dev_elems);
         const bool derived = !full && m.kind == 0 && (id / 3 == 1 || id / 3 == 3);
-        if (derived) {
-            // lean storage: E = D/eps and H = B/mu are formed here with the division the kernels use
-            const int c = id % 3, num = id / 3 == 1 ? c : 6 + c, den = id / 3 == 1 ? 12 + c : 15 + c;
-            FDTD_HIP(hipMemcpy(st.data(), fld[num], st.size() * sizeof(T), hipMemcpyDeviceToHost));
-            if (fld[den]) {
-                std::vector<T> dn(m.dev_elems);
-                FDTD_HIP(hipMemcpy(dn.data(), fld[den], dn.size() * sizeof(T), hipMemcpyDeviceToHost));
-                for (size_t q = 0; q < st.size(); ++q) st[q] = st[q] / dn[q];
-            } else {
-                const T m0 = (T)d.mu0;
-                for (size_t q = 0; q < st.size(); ++q) st[q] = st[q] / m0;
+        if (m.kind == 0) {
+            if (!derived) {
+                if (!m.dev) return fail(FDTD_ERR_STATE, "get_array(%d): array is not resident in this storage mode", id);
+                return get_field(m, m.dev, nullptr, (T)0, host);
             }
-        } else {
-            if (!m.dev) return fail(FDTD_ERR_STATE, "get_array(%d): array is not resident in this storage mode", id);
-            FDTD_HIP(hipMemcpy(st.data(), m.dev, st.size() * sizeof(T), hipMemcpyDeviceToHost));
+            // lean storage: E = D/eps and H = B/mu are formed on the way out with the division the kernels use
+            const int c = id % 3, num = id / 3 == 1 ? c : 6 + c, den = id / 3 == 1 ? 12 + c : 15 + c;
+            return get_field(m, fld[num], fld[den], fld[den] ? (T)0 : (T)d.mu0, host);
         }
+        // CPML auxiliaries and the source plane: small, transposed on the host
+        if (!m.dev) return fail(FDTD_ERR_STATE, "get_array(%d): array is not resident in this storage mode", id);
+        std::vector<T> st(m.dev_elems);
+        FDTD_HIP(hipMemcpy(st.data(), m.dev, st.size() * sizeof(T), hipMemcpyDeviceToHost));
         size_t o = 0;
         for (int p0 = 0; p0 < m.n[0]; ++p0) for (int p1 = 0; p1 < m.n[1]; ++p1) for (int p2 = 0; p2 < m.n[2]; ++p2, ++o) {
             bool owned;
