@@ -388,3 +388,40 @@ def test_random_configurations_half_step_kernels_equal_twin(seed, mode):
     for id_ in po.FIELDS3D + po.ALL_PHI3D:
         if eng.size(id_):
             util.assert_equal_arrays(eng.get(id_), tw.get(id_), f"seed {seed} mode {mode}: N={N} npml={npml} fp{prec} mu={has_mu}, array {id_}")
+
+
+def test_tiny_grids_equal_twin():
+    """Grids of 2, 3 and 5 cells per axis (the smallest the engine accepts), with and without a one-layer
+    CPML, every storage mode, both precisions, with and without a mu grid: 648 problems == the twin."""
+    import itertools
+    K = po.consts()
+    d = (5e-8, 6e-8, 7e-8)
+    dt = 5e-8 / (2 * K["c0"])
+    rng = np.random.default_rng(5)
+    steps, cases = 6, 0
+    for N in itertools.product((2, 3, 5), repeat=3):
+        for layers in (0, 1):
+            npml = tuple(layers if N[a // 2] > 2 * layers + 1 else 0 for a in range(6))
+            for mode, prec, has_mu in itertools.product((0, 1, 2), (32, 64), (False, True)):
+                kJ = int(rng.integers(0, N[2] + 1))
+                eng = fdtd_amd.Engine3D(N, npml, d, dt, K["mu0"], kJ, steps, precision=prec, mode=mode, has_mu=has_mu)
+                tw = po.Twin3D(prec, N, npml, d, dt, K["mu0"], kJ, steps, has_mu)
+                wf, mag = rng.standard_normal(steps), rng.random((N[0], N[1] + 1))
+                for be in (eng, tw):
+                    for a in range(3):
+                        for s_ in range(2):
+                            if npml[a * 2 + s_]:
+                                tabs = po.cpml_face(npml[a * 2 + s_], s_, d[a], d[a], dt)
+                                for k in range(6):
+                                    be.set(po.tab_id(a, s_, k), tabs[k])
+                    be.set(po.JX_WF, wf)
+                    be.set(po.JX_MAG, mag)
+                    be.fill_materials(7, K["eps0"], 4 * K["eps0"], K["mu0"], 3 * K["mu0"])
+                eng.step(0, steps)
+                tw.step(0, steps)
+                for id_ in po.FIELDS3D + po.ALL_PHI3D:
+                    if eng.size(id_):
+                        util.assert_equal_arrays(eng.get(id_), tw.get(id_), f"N={N} npml={npml} mode={mode} fp{prec} mu={has_mu}, array {id_}")
+                eng.close()
+                cases += 1
+    assert cases == 648
