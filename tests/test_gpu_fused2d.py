@@ -140,3 +140,48 @@ def test_fused2d_observables_equal_twin():
         eng.observe_accumulate(0.05, n % 10 == 0)
         tw.observe_accumulate(0.05, n % 10 == 0)
     util.assert_equal_arrays(eng.observe_rms(), tw.observe_rms(), "2-D fused RMS window")
+
+
+def test_tiny_grids_2d_equal_twin():
+    """2-D grids of 2, 3, 5 and 9 cells per axis, with and without a one-layer CPML, both step paths, both
+    precisions, with and without scattered dispersive cells: 256 problems == the twin."""
+    import itertools
+    K = po.consts()
+    dx, dz = 5e-8, 6e-8
+    dt = dx / (2 * K["c0"])
+    rng = np.random.default_rng(11)
+    steps, cases = 12, 0
+    for Nx, Nz in itertools.product((2, 3, 5, 9), repeat=2):
+        for layers in (0, 1):
+            npml = [layers if Nx > 2 * layers + 1 else 0] * 2 + [layers if Nz > 2 * layers + 1 else 0] * 2
+            for mode, prec, disp in itertools.product((0, 1), (32, 64), (0, 1)):
+                iJ, kJ = int(rng.integers(0, Nx)), int(rng.integers(0, Nz + 1))
+                eng = fdtd_amd.Engine2D(Nx, Nz, npml, dx, dz, dt, K["mu0"], K["eps0"], iJ, kJ, steps, precision=prec, mode=mode)
+                tw = po.Twin2D(prec, Nx, Nz, npml, dx, dz, dt, K["mu0"], K["eps0"], iJ, kJ, steps)
+                mask = (rng.random((Nx, Nz)) < 0.4) if disp else np.zeros((Nx, Nz), dtype=bool)
+                Cs = [np.where(mask, 0.02 * rng.random((Nx, Nz)), 0.0), np.where(mask, -1.9 + 0.01 * rng.random((Nx, Nz)), 0.0),
+                      np.where(mask, 1 + 0.01 * rng.random((Nx, Nz)), 0.0)]
+                jy = rng.standard_normal(steps) * 1e3
+                dd = (dx, dz)
+                for be in (eng, tw):
+                    for a in range(2):
+                        for s_ in range(2):
+                            if npml[a * 2 + s_]:
+                                tabs = po.cpml_face(npml[a * 2 + s_], s_, dd[a], dz, dt)
+                                for k in range(6):
+                                    be.set(po.D2_TAB + (a * 2 + s_) * 6 + k, tabs[k])
+                    for q in range(3):
+                        be.set(po.D2_C1 + q, Cs[q])
+                    be.set(po.D2_JY, jy)
+                eng.step(0, steps)
+                tw.step(0, steps)
+                what = f"2-D {Nx}x{Nz} npml={npml} fp{prec} mode {mode} dispersive={disp}"
+                if mode == MODE2D_FUSED:
+                    compare_2d(eng, tw.get, Nx, Nz, npml, mask, what)
+                else:
+                    for id_ in po.FIELDS2D + po.ALL_PHI2D:
+                        if eng.size(id_):
+                            util.assert_equal_arrays(eng.get(id_), tw.get(id_), f"{what}, array {id_}")
+                eng.close()
+                cases += 1
+    assert cases == 256
