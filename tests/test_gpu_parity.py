@@ -425,3 +425,37 @@ def test_tiny_grids_equal_twin():
                 eng.close()
                 cases += 1
     assert cases == 648
+
+
+@pytest.mark.parametrize("N,npml", [((140, 40, 150), (64, 60, 10, 12, 64, 64)), ((40, 140, 70), (5, 0, 64, 64, 33, 30)),
+                                    ((300, 20, 66), (64, 64, 3, 3, 64, 1)), ((64, 64, 64), (31, 32, 31, 32, 31, 32))])
+def test_maximum_cpml_layers_equal_twin(N, npml):
+    """Up to 64 layers per face (the table limit), CPML filling the grid but for one cell, strips wider
+    than an x tile: every storage mode and both precisions == the twin."""
+    import itertools
+    K = po.consts()
+    d = (5e-8, 6e-8, 7e-8)
+    dt = 5e-8 / (2 * K["c0"])
+    rng = np.random.default_rng(3)
+    steps = 7
+    for mode, prec in itertools.product((0, 1, 2), (32, 64)):
+        kJ, has_mu = int(rng.integers(0, N[2] + 1)), bool(rng.integers(0, 2))
+        eng = fdtd_amd.Engine3D(N, npml, d, dt, K["mu0"], kJ, steps, precision=prec, mode=mode, has_mu=has_mu)
+        tw = po.Twin3D(prec, N, npml, d, dt, K["mu0"], kJ, steps, has_mu)
+        wf, mag = rng.standard_normal(steps), rng.random((N[0], N[1] + 1))
+        for be in (eng, tw):
+            for a in range(3):
+                for s_ in range(2):
+                    if npml[a * 2 + s_]:
+                        tabs = po.cpml_face(npml[a * 2 + s_], s_, d[a], d[a], dt)
+                        for k in range(6):
+                            be.set(po.tab_id(a, s_, k), tabs[k])
+            be.set(po.JX_WF, wf)
+            be.set(po.JX_MAG, mag)
+            be.fill_materials(7, K["eps0"], 4 * K["eps0"], K["mu0"], 3 * K["mu0"])
+        eng.step(0, steps)
+        tw.step(0, steps)
+        for id_ in po.FIELDS3D + po.ALL_PHI3D:
+            if eng.size(id_):
+                util.assert_equal_arrays(eng.get(id_), tw.get(id_), f"N={N} npml={npml} mode={mode} fp{prec} mu={has_mu}, array {id_}")
+        eng.close()
