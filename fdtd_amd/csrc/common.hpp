@@ -118,6 +118,15 @@ __device__ __forceinline__ unsigned xcd_contiguous(unsigned bid, unsigned nblk) 
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + pos;
 }
 
+// In between: runs of G consecutive tiles stay on one XCD, successive runs go round the XCDs, so that
+// all XCDs stream from the same neighbourhood of memory while the tiles of a run still meet in one L2.
+__device__ __forceinline__ unsigned xcd_grouped(unsigned bid, unsigned nblk, unsigned G) {
+    const unsigned span = 8u * G, bulk = nblk / span * span;
+    if (bid >= bulk) return bid;                       // the tail keeps the order it is dealt in
+    const unsigned x = bid & 7u, pos = bid >> 3;
+    return ((pos / G) * 8u + x) * G + pos % G;
+}
+
 // Counter-based uniform in [0,1): synthetic materials reproducible on host and device.
 __host__ __device__ __forceinline__ double hash_unit(uint64_t seed, uint32_t stream, uint64_t index) {
     uint64_t z = seed + 0x9E3779B97F4A7C15ull * (index + 1) + ((uint64_t)stream << 56);

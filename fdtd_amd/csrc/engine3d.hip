@@ -249,7 +249,8 @@ struct Engine3 : fdtd3d_engine {
     T* obs_tmp = nullptr;             // two frame buffers of the same shape (allocated on first use)
     std::vector<double> tab_h;        // [3][2][6][kMaxLayers], fp64 master copy
     std::vector<T> wf;
-    int chunk = 8, remap = 1, wpb = 4;
+    static constexpr int kRemapAuto = 65536;
+    int chunk = 8, remap = kRemapAuto, wpb = 4;
     std::vector<void*> allocs;
 
     ~Engine3() override {
@@ -392,7 +393,7 @@ struct Engine3 : fdtd3d_engine {
         xwp = np[0][1] > 0 ? round_up(d.Nx - xp0, 4) : 0;
         if (fused) chunk = 24;           // the closing plane of a chunk is computed twice: longer chunks pay off
         if (const char* e = getenv("FDTD_Z_CHUNK")) { int c = atoi(e); if (c >= 1 && c <= 4096) chunk = c; }
-        if (const char* e = getenv("FDTD_XCD_REMAP")) remap = atoi(e) != 0;
+        if (const char* e = getenv("FDTD_XCD_REMAP")) { int v = atoi(e); if (v >= 0 && v <= 65536) remap = v; }
         if (const char* e = getenv("FDTD_FUSED_VEC")) { int v = atoi(e); if (v == V || v == V / 2) fvec = v; }
         if (const char* e = getenv("FDTD_ROWS_PER_GROUP")) { int w = atoi(e); if (w >= 1 && w <= 4) wpb = w; }
 
@@ -444,7 +445,7 @@ struct Engine3 : fdtd3d_engine {
     size_t device_bytes() override { return bytes; }
     int tune(int c, int r, int w) override {
         if (c >= 1 && c <= 4096) chunk = c;
-        if (r == 0 || r == 1) remap = r;
+        if (r >= 0 && r <= 65536) remap = r;
         if (w >= 1 && w <= 4) wpb = w;
         if (fused && w >= 2 && w <= 16) wpbf = w;
         return FDTD_OK;
@@ -792,7 +793,7 @@ struct Engine3 : fdtd3d_engine {
         a.dt = (T)d.dt; a.dtd[0] = (T)(d.dt / d.dx); a.dtd[1] = (T)(d.dt / d.dy); a.dtd[2] = (T)(d.dt / d.dz); a.mu0 = (T)d.mu0;
         a.nbx = px / (kLanes * V); a.nby = (ny1 + wpb - 1) / wpb; a.wpb = wpb;
         a.chunk = chunk;
-        a.remap = remap;
+        a.remap = remap == kRemapAuto ? 1 : remap;      // half-step kernels: contiguous ranges unless told otherwise
         return a;
     }
     // planes [kl0,kl1) of a part; E-half edge = lowest owned plane, H-half edge = highest owned
@@ -909,6 +910,9 @@ struct Engine3 : fdtd3d_engine {
                 for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) std::swap(a.phE[c][ax][sd], a.phEn[c][ax][sd]);
             }
         a.wpb = wpbf;
+        // tile order of the fused kernel: the x tiles of one row group share an XCD (their edge columns meet
+        // in its L2), successive row groups go round the XCDs, so that all XCDs stream from the same planes
+        if (remap == kRemapAuto) a.remap = std::max(2, px / (kLanes * fvec));
         a.nby = (ny1 + (wpbf - 1) - 1) / (wpbf - 1);
         a.kl0 = kl0; a.kl1 = kl1;
         a.kl_stop = hi; a.copy_top = last_rank ? 0 : 1;

@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(kLanes * MAXW) __attribute__((amdgpu_waves_per
     const unsigned lane = threadIdx.x & (kLanes - 1);
     const unsigned lo = lane * V;                        // this lane's columns inside the wave's segment
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), W = a.wpb;
-    unsigned bid = a.remap ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    unsigned bid = a.remap == 1 ? xcd_contiguous(blockIdx.x, gridDim.x) : (a.remap > 1 ? xcd_grouped(blockIdx.x, gridDim.x, (unsigned)a.remap) : blockIdx.x);
     const int bx = bid % a.nbx; bid /= a.nbx;
     const int by = bid % a.nby;
     const int bz = bid / a.nby;

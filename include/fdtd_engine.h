@@ -210,8 +210,10 @@ int fdtd3d_placement_probes(fdtd3d_handle h, double* ms_per_step, int cap);
 /* Bytes of device memory held by the handle. */
 size_t fdtd3d_device_bytes(fdtd3d_handle h);
 
-/* Launch-shape knobs (no effect on results): planes marched per workgroup (1..4096), XCD-contiguous
- * tile order (0/1), rows (= waves) per workgroup (1..4 for the half-step kernels; 2..16 for the
+/* Launch-shape knobs (no effect on results): planes marched per workgroup (1..4096); tile order over
+ * the 8 XCDs (0: as dealt, 1: each XCD a contiguous range of tiles, 2..65535: runs of that many
+ * consecutive tiles per XCD, 65536: automatic, the default -- for the fused kernel runs of one row
+ * group's x tiles); rows (= waves) per workgroup (1..4 for the half-step kernels; 2..16 for the
  * fused kernel, whose last wave recomputes the first row of the next tile); a value outside its
  * range keeps the current setting.  The environment variables FDTD_Z_CHUNK / FDTD_XCD_REMAP / FDTD_ROWS_PER_GROUP
  * set them at creation; FDTD_FUSED_VEC (elements per lane of the fused kernel: 4 or 2 in fp32, 2 or 1
