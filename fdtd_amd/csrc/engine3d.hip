@@ -793,7 +793,9 @@ struct Engine3 : fdtd3d_engine {
         a.dt = (T)d.dt; a.dtd[0] = (T)(d.dt / d.dx); a.dtd[1] = (T)(d.dt / d.dy); a.dtd[2] = (T)(d.dt / d.dz); a.mu0 = (T)d.mu0;
         a.nbx = px / (kLanes * V); a.nby = (ny1 + wpb - 1) / wpb; a.wpb = wpb;
         a.chunk = chunk;
-        a.remap = remap == kRemapAuto ? 1 : remap;      // half-step kernels: contiguous ranges unless told otherwise
+        // half-step kernels: runs of one row group's x tiles per XCD (measured at 1024^3: LEAN 21.4 ms against
+        // 23.5 ms with contiguous ranges; with E and H resident too, four row groups per run are slightly better)
+        a.remap = remap == kRemapAuto ? (full ? 4 : 1) * std::max(2, px / (kLanes * V)) : remap;
         return a;
     }
     // planes [kl0,kl1) of a part; E-half edge = lowest owned plane, H-half edge = highest owned

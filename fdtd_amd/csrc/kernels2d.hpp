@@ -64,7 +64,7 @@ __device__ __forceinline__ Tile2<T> decode_tile2(const K2<T>& a) {
     Tile2<T> t;
     t.lane = threadIdx.x & (kLanes - 1);
     const int w = threadIdx.x >> 6;
-    const unsigned bid = a.remap ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    const unsigned bid = a.remap == 1 ? xcd_contiguous(blockIdx.x, gridDim.x) : (a.remap > 1 ? xcd_grouped(blockIdx.x, gridDim.x, (unsigned)a.remap) : blockIdx.x);
     const int bx = bid % a.nbx, bz = bid / a.nbx;
     const int tx = bx * kWavesPerBlock + w;
     t.ok = tx < a.ntx;

@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(kLanes * kStack2D) k2_fused(const K2F<T> a) {
     ArgBlock2<T> ap = (ArgBlock2<T>)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & (kLanes - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned bid = a.remap ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    const unsigned bid = a.remap == 1 ? xcd_contiguous(blockIdx.x, gridDim.x) : (a.remap > 1 ? xcd_grouped(blockIdx.x, gridDim.x, (unsigned)a.remap) : blockIdx.x);
     const int bx = bid % a.nbx, bz = bid / a.nbx;
     // the waves of a workgroup sit on consecutive row chunks of one x tile: the row that closes a wave's
     // chunk is the first row of the wave above, which hands its Ey_new over through LDS (one barrier per

@@ -203,7 +203,7 @@ __device__ __forceinline__ Lane3<T, V> decode_lane(const K3<T>& a) {
     Lane3<T, V> t;
     t.lane = threadIdx.x & (kLanes - 1);
     const int w = threadIdx.x >> 6;
-    unsigned bid = a.remap ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    unsigned bid = a.remap == 1 ? xcd_contiguous(blockIdx.x, gridDim.x) : (a.remap > 1 ? xcd_grouped(blockIdx.x, gridDim.x, (unsigned)a.remap) : blockIdx.x);
     const int bx = bid % a.nbx; bid /= a.nbx;
     const int by = bid % a.nby;
     const int bz = bid / a.nby;
