@@ -11,13 +11,20 @@ __device__ __forceinline__ unsigned xcd_contiguous(unsigned bid, unsigned nblk) 
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + pos;
 }
 
+__device__ __forceinline__ unsigned xcd_grouped(unsigned bid, unsigned nblk, unsigned G) {
+    const unsigned span = 8u * G, bulk = nblk / span * span;
+    if (bid >= bulk) return bid;
+    const unsigned x = bid & 7u, pos = bid >> 3;
+    return ((pos / G) * 8u + x) * G + pos % G;
+}
+
 // block = WX x-tiles (64 lanes each) times WY rows; marches chunk planes
 template <int R, int W>
 __global__ void __launch_bounds__(1024) k_march(Ptrs a, int px4, int ny, int nz, int chunk, int WX, int WY, int nbx, int nby, int nbz, int remap, int order) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wx = w % WX, wy = w / WX;
     unsigned bid = blockIdx.x;
-    if (remap) bid = xcd_contiguous(bid, gridDim.x);
+    if (remap == 1) bid = xcd_contiguous(bid, gridDim.x); else if (remap > 1) bid = xcd_grouped(bid, gridDim.x, remap);
     int bx, by, bz;
     if (order == 0) { bx = bid % nbx; bid /= nbx; by = bid % nby; bz = bid / nby; }
     else { bz = bid % nbz; bid /= nbz; bx = bid % nbx; by = bid / nbx; }       // z fastest: consecutive blocks = stacked chunks
@@ -71,7 +78,7 @@ int main() {
     fflush(stdout);
     const double mb = (double)n4 * 16 * 24;
     struct G { int WX, WY, chunk, remap, order; };
-    const G gs[] = {{1, 16, 24, 1, 0}, {1, 16, 24, 0, 0}, {2, 8, 24, 1, 0}, {4, 4, 24, 1, 0}, {4, 4, 24, 0, 0}, {1, 16, 8, 1, 0}, {4, 4, 8, 1, 0}, {1, 16, 1, 1, 0}, {4, 4, 1, 1, 0}, {4, 4, 1, 0, 0},
+    const G gs[] = {{1, 16, 24, 4, 0}, {1, 16, 24, 2, 0}, {1, 16, 24, 8, 0}, {1, 15, 24, 4, 0}, {4, 4, 24, 4, 0}, {1, 16, 24, 1, 0}, {1, 16, 24, 0, 0}, {2, 8, 24, 1, 0}, {4, 4, 24, 1, 0}, {4, 4, 24, 0, 0}, {1, 16, 8, 1, 0}, {4, 4, 8, 1, 0}, {1, 16, 1, 1, 0}, {4, 4, 1, 1, 0}, {4, 4, 1, 0, 0},
                     {1, 16, 24, 0, 1}, {4, 4, 24, 0, 1}, {1, 8, 24, 1, 0}, {1, 4, 24, 1, 0}, {4, 2, 24, 1, 0}, {4, 1, 24, 1, 0}, {1, 16, 64, 1, 0}, {4, 4, 64, 1, 0}};
     for (const G& g : gs) {
         const int nbx = px4 / (64 * g.WX), nby = (ny + g.WY - 1) / g.WY, nbz = (nz + g.chunk - 1) / g.chunk;
