@@ -22,15 +22,17 @@ ap.add_argument("--chunk", type=int, default=0)
 ap.add_argument("--rows", type=int, default=0)
 ap.add_argument("--precision", type=int, default=32)
 ap.add_argument("--no-mu", action="store_true")
+ap.add_argument("--npml", type=int, default=20)
 args = ap.parse_args()
 
 n = args.n
 K = fs.constants()
 d = (1053e-9 / 20,) * 3
 dt = d[0] / (K["c0"] * 2)
-eng = fdtd_amd.Engine3D((n, n, n), (20,) * 6, d, dt, K["mu0"], 20, 4096, precision=args.precision, has_mu=not args.no_mu,
+eng = fdtd_amd.Engine3D((n, n, n), (args.npml,) * 6, d, dt, K["mu0"], 20, 4096, precision=args.precision, has_mu=not args.no_mu,
                         mode={"full": 0, "lean": 1, "fused": 2}[args.mode])
-fs.load_cpml3d(eng, d, dt)
+if args.npml:
+    fs.load_cpml3d(eng, d, dt)
 wf, mag = fs.default_source3d(n, n, 4096, d, dt)
 eng.set(fdtd_amd.engine.JX_WF, wf)
 eng.set(fdtd_amd.engine.JX_MAG, mag)
