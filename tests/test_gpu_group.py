@@ -113,6 +113,38 @@ def test_group_random_configurations_equal_twin(seed):
     g.close()
 
 
+@pytest.mark.parametrize("slabs,mode", [(5, E.MODE_FUSED), (16, E.MODE_FUSED), (8, E.MODE_LEAN), (16, E.MODE_FULL)])
+def test_group_many_slabs_midsize(slabs, mode):
+    """300 x 100 x 130 cells cut into up to 16 slabs (kernels long enough for the copies to overlap them),
+    30 steps in two calls: same checksums as one engine on the whole grid."""
+    from fdtd_amd import setup as fs
+    N, steps = (300, 100, 130), 30
+    K = fs.constants()
+    d = (1053e-9 / 20,) * 3
+    dt = d[0] / (2 * K["c0"])
+    ids = (E.DX, E.DY, E.DZ, E.BX, E.BY, E.BZ)
+
+    def prepare(whole, members):
+        wf, mag = fs.default_source3d(N[0], N[1], steps, d, dt)
+        for m in members:
+            fs.load_cpml3d(m, d, dt)
+            m.set(E.JX_WF, wf)
+            m.set(E.JX_MAG, mag)
+        whole.fill_materials(99, K["eps0"], 4 * K["eps0"], K["mu0"], 2 * K["mu0"])
+
+    one = fdtd_amd.Engine3D(N, (10,) * 6, d, dt, K["mu0"], 12, steps, precision=32, has_mu=True, mode=mode)
+    prepare(one, [one])
+    one.step(0, steps)
+    want = [one.checksum(i) for i in ids]
+    one.close()
+    g = E.EngineGroup3D(N, (10,) * 6, d, dt, K["mu0"], 12, steps, slabs, precision=32, has_mu=True, mode=mode)
+    prepare(g, g.members)
+    g.step(0, 7)
+    g.step(7, steps - 7)
+    assert [g.checksum(i) for i in ids] == want
+    g.close()
+
+
 def test_group_refusals():
     meta, _, _, _ = util.load_fixture("g1_3d_cpml")
     with pytest.raises(E.EngineError, match="cannot split"):
