@@ -228,8 +228,11 @@ __global__ void __launch_bounds__(kLanes * MAXW) __attribute__((amdgpu_waves_per
         else { hx = divide<T, V>(bo[0], a.mu0); hy = divide<T, V>(bo[1], a.mu0); hz = divide<T, V>(bo[2], a.mu0); }
         P hx_jm = zero_pack<T, V>(), hz_jm = zero_pack<T, V>();
         if (j >= 1) { hx_jm = load_hu<T, V, MU>(ap, 0, ro - px, lo, a.mu0); hz_jm = load_hu<T, V, MU>(ap, 2, ro - px, lo, a.mu0); }
-        P dx = ldg<T, V>(ap->D[0] + ro, lo), dy = ldg<T, V>(ap->D[1] + ro, lo), dz = ldg<T, V>(ap->D[2] + ro, lo);
-        const P epx = ldg<T, V>(ap->eps[0] + ro, lo), epy = ldg<T, V>(ap->eps[1] + ro, lo), epz = ldg<T, V>(ap->eps[2] + ro, lo);
+        // the halo row only has to deliver Ex and Ez: its Dy and eps_y loads are pointed at the x components it
+        // reads anyway (same cache lines, nothing new from memory); what it computes from them is never used
+        const int cy = halo_row ? 0 : 1;
+        P dx = ldg<T, V>(ap->D[0] + ro, lo), dy = ldg<T, V>(ap->D[cy] + ro, lo), dz = ldg<T, V>(ap->D[2] + ro, lo);
+        const P epx = ldg<T, V>(ap->eps[0] + ro, lo), epy = ldg<T, V>(ap->eps[cy] + ro, lo), epz = ldg<T, V>(ap->eps[2] + ro, lo);
         T hy_l = __shfl_up(hy.v[V - 1], 1), hz_l = __shfl_up(hz.v[V - 1], 1);
         if (lane == 0) {
             hy_l = c0 > 0 ? load_hu1<T, MU>(ap, 1, ro - 1, a.mu0) : (T)0;
