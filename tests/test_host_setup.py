@@ -75,3 +75,24 @@ def test_create_fails_loudly_without_device_or_with_bad_arguments():
     if not has_gpu:
         with pytest.raises(fdtd_amd.EngineError, match="device|HIP|hip"):
             fdtd_amd.Engine3D((8, 8, 8), (0,) * 6, (1e-7,) * 3, 1e-16, K["mu0"], 4, 3)
+
+
+def test_group_and_device_count_refuse_without_touching_a_device():
+    """Argument checks of the slab-group entry points come before any device call, so they answer on a
+    box without a GPU too; fdtd_device_count() reports what is visible (0 here on the CPU box)."""
+    import ctypes as C
+    from fdtd_amd import engine as E
+    L = fdtd_amd.lib()
+    h = C.c_void_p()
+    assert L.fdtd3d_group_create(None, 2, None, C.byref(h)) == 1 and not h.value
+    desc = E.Desc3D(C.sizeof(E.Desc3D), 16, 16, 16, (C.c_int32 * 6)(0, 0, 0, 0, 0, 0), 4, 3, 32, 0, 2, 0, 16, -1, 1e-7, 1e-7, 1e-7, 1e-16, 1.2566e-6)
+    assert L.fdtd3d_group_create(C.byref(desc), 0, None, C.byref(h)) == 1 and b"cannot split" in L.fdtd_last_error()
+    assert L.fdtd3d_group_create(C.byref(desc), 17, None, C.byref(h)) == 1
+    assert L.fdtd3d_group_step(None, 0, 1) == 1 and L.fdtd3d_group_sync(None) == 1
+    assert L.fdtd3d_group_slabs(None) == 0 and L.fdtd3d_group_destroy(None) == 0
+    n = L.fdtd_device_count()
+    try:
+        import torch
+        assert n == (torch.cuda.device_count() if torch.cuda.is_available() else 0)
+    except ImportError:
+        assert n >= 0
