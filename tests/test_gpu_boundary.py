@@ -99,3 +99,36 @@ def test_calls_leave_the_callers_device_current():
     eng.get(E.DX)
     assert torch.cuda.current_device() == before
     eng.close()
+
+
+@pytest.mark.parametrize("mode", [E.MODE_FULL, E.MODE_LEAN, E.MODE_FUSED])
+def test_empty_waveform_and_steps_past_its_end(mode):
+    """No waveform at all: nothing is ever injected and the zero state stays zero.  A waveform shorter than
+    the run: steps past its end inject nothing, exactly like the twin (the reference indexes its waveform
+    with the step number, fdtd3d/src/FDTD3D.cpp:482, and never runs past it)."""
+    from oracle import pyoracle as po
+    quiet = make3(n_wf=0, mode=mode)
+    assert quiet.size(E.JX_WF) == 0
+    quiet.set(E.JX_WF, np.zeros(0))
+    quiet.set(E.JX_MAG, np.ones((24, 21)))
+    quiet.step(0, 5)
+    assert quiet.sumsq(E.DX) == 0.0 and quiet.sumsq(E.BY) == 0.0
+    n_wf, steps = 4, 9
+    eng = make3(n_wf=n_wf, mode=mode)
+    tw = po.Twin3D(32, GOOD3["N"], GOOD3["npml"], GOOD3["d"], GOOD3["dt"], GOOD3["mu0"], GOOD3["k_Jx"], n_wf, False)
+    rng = np.random.default_rng(8)
+    wf, mag = rng.standard_normal(n_wf), rng.random((24, 21))
+    for be in (eng, tw):
+        for a in range(3):
+            for s_ in range(2):
+                tabs = po.cpml_face(4, s_, GOOD3["d"][a], GOOD3["d"][a], GOOD3["dt"])
+                for k in range(6):
+                    be.set(po.tab_id(a, s_, k), tabs[k])
+        be.set(E.JX_WF, wf)
+        be.set(E.JX_MAG, mag)
+        be.fill_materials(3, 8.854e-12, 3 * 8.854e-12, MU0, MU0)
+    eng.step(0, steps)
+    tw.step(0, steps)
+    for id_ in (E.DX, E.DY, E.DZ, E.BX, E.BY, E.BZ):
+        a, b = eng.get(id_), tw.get(id_)
+        assert np.array_equal(a, b) and (id_ != E.DX or np.abs(a).max() > 0)
