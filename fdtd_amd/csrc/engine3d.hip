@@ -395,12 +395,12 @@ struct Engine3 : fdtd3d_engine {
         if (fused) {
             // The closing plane of a chunk is computed twice, so long chunks pay off -- once there are enough
             // workgroups to fill 256 CUs several times over.  Small grids (the reference's own 200^3) get shorter
-            // chunks, down to 4 planes, and below about a thousand workgroups 8 instead of 16 rows per group
-            // (200^3: 0.21 ms per step instead of 0.39).
+            // chunks, down to 4 planes, and launches that stay below 1600 workgroups 8 instead of 16 rows per
+            // group (200^3: 0.21 ms per step instead of 0.39).
             const int per_chunk = (px / (kLanes * fvec)) * ((ny1 + 14) / 15);
             const int chunks_wanted = (1400 + per_chunk - 1) / per_chunk;
             chunk = std::max(4, std::min(24, nzl / std::max(1, chunks_wanted)));
-            if (per_chunk * ((nzl + 3) / 4) < 1024) wpbf = 8;
+            if (per_chunk * ((nzl + chunk - 1) / chunk) < 1600) wpbf = 8;
         }
         if (const char* e = getenv("FDTD_Z_CHUNK")) { int c = atoi(e); if (c >= 1 && c <= 4096) chunk = c; }
         if (const char* e = getenv("FDTD_XCD_REMAP")) { int v = atoi(e); if (v >= 0 && v <= 65536) remap = v; }
