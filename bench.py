@@ -22,6 +22,15 @@ Environment knobs for experiments (the defaults are the graded configuration):
   FDTD_BENCH_MODE=lean   two half-step kernels over D,B-only storage instead of the fused default
   FDTD_BENCH_MODE=full   two half-step kernels, E and H resident too (the reference's storage)
 
+roofline.achieved prices the step at the ALGORITHMIC bytes of the reference's formulation (D, E, B, H, eps, mu
+all resident: 30 words per cell and step with a mu grid, 27 without), whatever the kernels really move;
+roofline.own_model_* prices it at the words the chosen storage mode has to move (fused: 18 / 15), and
+roofline.traffic is the HBM traffic a rocprofv3 PMC pass measured on this very build and launch shape (null
+when profiles/ holds no pass stamped with this build's kernel sources and launch shape).
+For N > 1 the line carries multi_gpu: backend and world size actually seen, and per rank its device, the device
+time of every kind of launch, the time its stream sat idle in front of the launches that wait for a ghost plane,
+and the host time spent waiting for exchanges.
+
 Started WITHOUT torch.distributed.run but with --gpus N > 1, the same workload runs as ONE process
 driving N GPUs through a slab group (fdtd3d_group_*: streams, events, peer copies instead of RCCL);
 the JSON line then says so in config.decomposition.
@@ -89,6 +98,89 @@ def cpu_baseline():
             "sample": f"CPU restatement of the reference loops (fp64), 128^3 with eps/mu grids and 20-layer CPML, {steps} steps in {el:.1f} s"}
 
 
+KIND_NAME = {0: "half_e", 1: "half_h", 2: "fused"}
+PART_NAME = {0: "all", 1: "edge", 2: "interior", 3: "top"}
+
+
+def byte_models(has_mu: bool, mode_name: str):
+    """(bytes per cell of the E-half, of the H-half) in the reference's formulation, and the bytes per cell
+    and step the storage mode has to move at least; fp32."""
+    ref_e, ref_h = 15 * 4, (12 + (3 if has_mu else 0)) * 4
+    # fused: D, B read and written once, eps (and mu) read once; lean: D (B) read and written by its own half
+    # and read by the other, eps and mu read by both halves; full: the reference's traffic
+    own_words = {"fused": 15 + (3 if has_mu else 0), "lean": 18 + (6 if has_mu else 3), "full": 27 + (3 if has_mu else 0)}[mode_name]
+    return ref_e, ref_h, own_words * 4
+
+
+def launch_summary(eng, steps: int):
+    """Per step: device milliseconds per kind of launch, and the idle time of the launch stream in front of
+    each kind (on a slab the gap in front of an edge launch is the wait for a ghost plane)."""
+    tl = eng.kernel_timeline()
+    dur, gap, cnt = {}, {}, {}
+    prev_end = None
+    for kind, part, t0, d in tl:
+        name = f"{KIND_NAME.get(kind, kind)}_{PART_NAME.get(part, part)}"
+        dur[name] = dur.get(name, 0.0) + d
+        cnt[name] = cnt.get(name, 0) + 1
+        if prev_end is not None:
+            gap[name] = gap.get(name, 0.0) + max(0.0, t0 - prev_end)
+        prev_end = t0 + d
+    k = max(steps, 1)
+    span = (tl[-1][2] + tl[-1][3]) / k if tl else 0.0
+    return {"launch_ms_per_step": {n: v / k for n, v in dur.items()}, "launches_per_step": {n: v / k for n, v in cnt.items()},
+            "stream_idle_ms_per_step_before": {n: v / k for n, v in gap.items()}, "first_to_last_launch_ms_per_step": span}
+
+
+def stamped_traffic(eng, mode_name: str, dom: str, applies: bool):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ -- only if
+    they were taken on this build (same kernel sources) with this launch shape."""
+    if not applies:
+        return None, "no PMC pass for this configuration"
+    from fdtd_amd.engine import kernel_source_digest
+    path = os.path.join(ROOT, "profiles", f"r2_traffic_1024_{mode_name}.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        if rec.get("kernel_source_sha256") != kernel_source_digest():
+            return None, "kernel sources changed since the PMC pass"
+        if rec.get("launch_shape") != eng.launch_shape():
+            return None, "launch shape differs from the PMC pass"
+        return rec["per_launch"][dom]["total_bytes"], os.path.relpath(path, ROOT)
+    except (OSError, KeyError, ValueError):
+        return None, "no PMC pass recorded"
+
+
+def roofline_block(eng, mode_name, has_mu, cells_local, steps, applies_traffic, world, total_cells, el):
+    """The roofline object for one engine from its launch timers (call launch_summary first: this consumes them)."""
+    n_e, ms_e = eng.kernel_time(0)
+    n_h, ms_h = eng.kernel_time(1)
+    n_f, ms_f = eng.kernel_time(2)
+    ref_e, ref_h, own = byte_models(has_mu, mode_name)
+    k = max(steps, 1)
+    t_e, t_h, t_f = ms_e / k * 1e-3, ms_h / k * 1e-3, ms_f / k * 1e-3          # device seconds per step per kernel kind
+    if mode_name == "fused":
+        # per step the fused launches (one; or edge + top + interior on a slab) visit every owned cell once, and on a
+        # slab below another one the single-plane H kernel finishes the top layer: all of it is the step's kernel time
+        dom, dom_bytes, t_dom, own_bytes = "k3_fused", ref_e + ref_h, t_f + t_h, own
+    elif t_e >= t_h:
+        dom, dom_bytes, t_dom, own_bytes = "k3_half_e", ref_e, t_e, own // 2
+    else:
+        dom, dom_bytes, t_dom, own_bytes = "k3_half_h", ref_h, t_h, own // 2
+    ach = cells_local * dom_bytes / t_dom / 1e9 if t_dom > 0 else 0.0
+    own_rate = cells_local * own_bytes / t_dom / 1e9 if t_dom > 0 else 0.0
+    traffic, traffic_src = stamped_traffic(eng, mode_name, dom, applies_traffic)
+    return {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_rate_GBs": (traffic / t_dom / 1e9) if (traffic and t_dom > 0) else None,   # bytes really moved per second
+            "traffic_frac_of_peak": (traffic / t_dom / 1e9 / HBM_PEAK_GBS) if (traffic and t_dom > 0) else None,
+            "algorithmic_bytes_per_launch": cells_local * dom_bytes, "algorithmic_bytes_per_cell": dom_bytes,
+            "own_model_bytes_per_cell": own_bytes, "own_model_GBs": own_rate, "own_model_frac": own_rate / HBM_PEAK_GBS,
+            "cells_per_launch": cells_local, "kernel_ms_per_step": t_dom * 1e3,
+            "ms_per_step_e_half": t_e * 1e3, "ms_per_step_h_half": t_h * 1e3, "ms_per_step_fused": t_f * 1e3,
+            "launches_per_step": {"k3_half_e": n_e / k, "k3_half_h": n_h / k, "k3_fused": n_f / k},
+            "whole_step_frac": (total_cells * (ref_e + ref_h) * steps / el / 1e9) / (HBM_PEAK_GBS * world) if el > 0 else 0.0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,7 +216,6 @@ def main():
     mode_name = os.environ.get("FDTD_BENCH_MODE", "fused")
     if mode_name not in ("fused", "lean", "full"):
         raise SystemExit(f"FDTD_BENCH_MODE={mode_name}: expected fused, lean or full")
-    lean = mode_name == "lean"
     Nx = Ny = n_edge
     Nz = int(os.environ.get("FDTD_BENCH_NZ", str(n_edge * world)))
     npml = (20,) * 6
@@ -163,62 +254,48 @@ def main():
         stepper.finish()
     fence()
     eng.kernel_timing(True)
+    slab.WAIT_CLOCK.update(seconds=0.0, calls=0)
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
     if stepper is not None:
         stepper.finish()
+    t_issue = time.perf_counter() - t0          # host time until every launch and exchange of the timed steps was issued
     fence()
-    el = time.perf_counter() - t0
+    el_own = time.perf_counter() - t0
     eng.kernel_timing(False)
+    el = el_own
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
-    # per-kernel device time from HIP events recorded on the launch stream
-    n_e, ms_e = eng.kernel_time(0)
-    n_h, ms_h = eng.kernel_time(1)
-    n_f, ms_f = eng.kernel_time(2)
+    # per-launch device time from HIP events recorded on the launch stream
     cells_local = Nx * Ny * (z_hi - z_lo)
-    # algorithmic bytes per cell, fp32, in the reference's formulation whatever the kernels really move:
-    # E-half reads H(3) + r/w D(6) + eps(3) + writes E(3) = 15 words; H-half reads E(3) + r/w B(6) + writes
-    # H(3) = 12 words, +3 for the mu grid.  A fused launch does both halves of its cells.
-    bytes_e, bytes_h = 15 * 4, (12 + (3 if has_mu else 0)) * 4
-    steps_ = max(args.steps, 1)
-    t_e, t_h, t_f = ms_e / steps_ * 1e-3, ms_h / steps_ * 1e-3, ms_f / steps_ * 1e-3   # device seconds per step per kernel kind
-    if mode_name == "fused":
-        # per step the fused launches (one, or lowest chunk + rest on a slab) together visit every owned cell once
-        dom, dom_bytes, t_dom = "k3_fused", bytes_e + bytes_h, t_f
-    elif t_e >= t_h:
-        dom, dom_bytes, t_dom = "k3_half_e", bytes_e, t_e
-    else:
-        dom, dom_bytes, t_dom = "k3_half_h", bytes_h, t_h
-    ach = cells_local * dom_bytes / t_dom / 1e9
+    launches = launch_summary(eng, args.steps)
+    roof = roofline_block(eng, mode_name, has_mu, cells_local, args.steps, has_mu and n_edge == 1024 and world == 1,
+                          world, Nx * Ny * Nz, el)
     sums = [eng.sumsq(i) for i in (fdtd_amd.engine.DX, fdtd_amd.engine.BY)]
     finite = all(v == v and v < float("inf") for v in sums)
     ex_energy = sums[0]
     # order-independent checksum of Dx over the whole grid: equal for every decomposition of the same problem
     csum = eng.checksum(fdtd_amd.engine.DX)
+    multi = None
     if world > 1:
+        k = max(args.steps, 1)
+        mine = {"rank": rank, "device": torch.cuda.current_device(), "device_name": torch.cuda.get_device_name(),
+                "layers": [z_lo, z_hi], "wall_ms_per_step": el_own / k * 1e3, "host_issue_ms_per_step": t_issue / k * 1e3,
+                "host_wait_ms_per_step": slab.WAIT_CLOCK["seconds"] / k * 1e3, "exchange_waits_per_step": slab.WAIT_CLOCK["calls"] / k,
+                "kernel_ms_per_step": roof["kernel_ms_per_step"], "placement_probe_ms": [round(v, 3) for v in eng.placement_probes()],
+                "checksum_dx": csum, **launches}
         parts = [None] * world
-        dist.all_gather_object(parts, csum)
-        csum = sum(parts) % 2 ** 64
-
-    # HBM-side bytes per launch from the PMC passes recorded under profiles/ (the counters cannot be
-    # read from inside this process); only reported when this run is the configuration they were taken on
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", f"r1_traffic_1024_{mode_name}.json")) as f:
-            rec = json.load(f)
-        if has_mu and n_edge == 1024 and world == 1:
-            traffic = rec["per_launch"][dom]["total_bytes"]
-    except (OSError, KeyError, ValueError):
-        traffic = None
+        dist.all_gather_object(parts, mine)
+        csum = sum(p["checksum_dx"] for p in parts) % 2 ** 64
+        multi = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "per_rank": parts,
+                 "slowest_rank": max(parts, key=lambda p: p["wall_ms_per_step"])["rank"]}
 
     if rank == 0:
         total_cells = Nx * Ny * Nz
         value = total_cells * args.steps / el / 1e6
-        bytes_step = bytes_e + bytes_h
         out = {
             "metric": "Mcell-updates/s", "value": value, "unit": "Mcell-updates/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
@@ -229,18 +306,14 @@ def main():
                        "storage": {"fused": "D,B resident in two buffer sets; E=D/eps, H=B/mu formed in registers; one kernel per step",
                                    "lean": "D,B resident; E=D/eps, H=B/mu recomputed in the consuming kernel; two kernels per step",
                                    "full": "D,E,B,H resident; two kernels per step"}[mode_name],
+                       "launch_shape": eng.launch_shape(),
                        "device_bytes_per_gpu": eng.device_bytes(), "placement_probe_ms": [round(v, 3) for v in eng.placement_probes()]},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_rate_GBs": (traffic / t_dom / 1e9) if traffic else None,   # bytes really moved per second
-                         "algorithmic_bytes_per_launch": cells_local * dom_bytes,
-                         "algorithmic_bytes_per_cell": dom_bytes,
-                         "cells_per_launch": cells_local,
-                         "ms_per_step_e_half": t_e * 1e3, "ms_per_step_h_half": t_h * 1e3, "ms_per_step_fused": t_f * 1e3,
-                         "launches_per_step": {"k3_half_e": n_e / steps_, "k3_half_h": n_h / steps_, "k3_fused": n_f / steps_},
-                         "whole_step_frac": (cells_local * world * bytes_step * args.steps / el / 1e9) / (HBM_PEAK_GBS * world)},
+            "roofline": roof,
+            "launches": launches,
             "checks": {"finite": bool(finite), "sumsq_dx_rank0": ex_energy, "checksum_dx": csum},
         }
+        if multi is not None:
+            out["multi_gpu"] = multi
         if world == 1 and os.environ.get("FDTD_BENCH_CPU", "1") != "0":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
@@ -283,18 +356,19 @@ def main_group(args):
         m.kernel_timing(True)
     t0 = time.perf_counter()
     g.step(args.warmup, args.steps)
+    t_issue = time.perf_counter() - t0
     g.sync()
     el = time.perf_counter() - t0
-    bytes_step = 15 * 4 + (12 + (3 if has_mu else 0)) * 4
-    kind = 2 if mode_name == "fused" else 0
-    per_member = []
-    for m, (lo, hi) in zip(g.members, g.bounds()):
+    per_slab, roofs = [], []
+    for r, (m, (lo, hi)) in enumerate(zip(g.members, g.bounds())):
         m.kernel_timing(False)
-        _, ms = m.kernel_time(kind)
-        if mode_name != "fused":
-            ms += m.kernel_time(1)[1]
-        per_member.append(Nx * Ny * (hi - lo) * bytes_step / (ms / max(args.steps, 1) * 1e-3) / 1e9 if ms > 0 else 0.0)
-    ach = min(per_member)                    # the slowest slab's kernels set the pace
+        launches = launch_summary(m, args.steps)
+        roof = roofline_block(m, mode_name, has_mu, Nx * Ny * (hi - lo), args.steps, False, len(set(devices)), Nx * Ny * Nz, el)
+        roofs.append(roof)
+        per_slab.append({"slab": r, "device": devices[r], "layers": [lo, hi], "kernel_ms_per_step": roof["kernel_ms_per_step"],
+                         "placement_probe_ms": [round(v, 3) for v in m.placement_probes()], **launches})
+    roof = min(roofs, key=lambda q: q["achieved"])          # the slowest slab's kernels set the pace
+    roof["per_slab_GBs"] = [q["achieved"] for q in roofs]
     sums = [g.sumsq(i) for i in (E.DX, E.BY)]
     out = {
         "metric": "Mcell-updates/s", "value": Nx * Ny * Nz * args.steps / el / 1e6, "unit": "Mcell-updates/s", "n_gpus": N,
@@ -302,12 +376,12 @@ def main_group(args):
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"fdtd3d {Nx}x{Ny}x{Nz} ({Nz // N} layers per GPU), heterogeneous eps{'/mu' if has_mu else ''} grid, "
                                "20-layer CPML on six faces, Gaussian sheet source",
-                   "grid": [Nx, Ny, Nz], "cpml_layers": 20, "mu_grid": has_mu,
+                   "grid": [Nx, Ny, Nz], "cpml_layers": 20, "mu_grid": has_mu, "launch_shape": g.members[0].launch_shape(),
                    "decomposition": f"z-slabs x{N}, one process, slab group on devices {devices}", "storage": mode_name},
-        "roofline": {"bound": "hbm", "kernel": "k3_fused" if mode_name == "fused" else "k3_half_e+k3_half_h", "achieved": ach,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_cell": bytes_step, "per_slab_GBs": per_member,
-                     "whole_step_frac": (Nx * Ny * Nz * bytes_step * args.steps / el / 1e9) / (HBM_PEAK_GBS * len(set(devices)))},
+        "roofline": roof,
+        "multi_gpu": {"backend": "one host thread: HIP streams and events, hipMemcpyPeerAsync between neighbouring devices",
+                      "world_size": N, "devices_visible": ndev, "host_issue_ms_per_step": t_issue / max(args.steps, 1) * 1e3,
+                      "per_rank": per_slab},
         "checks": {"finite": all(v == v and v < float("inf") for v in sums), "sumsq_dx": sums[0], "checksum_dx": g.checksum(E.DX)},
     }
     print(json.dumps(out))

@@ -24,9 +24,9 @@ hipEvent_t KernelTimer::get() {
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
-void KernelTimer::begin(int kind, hipStream_t s) {
+void KernelTimer::begin(int kind, hipStream_t s, int part) {
     if (!enabled) return;
-    Rec r{get(), get(), kind};
+    Rec r{get(), get(), kind, part};
     if (!r.a || !r.b) { enabled = false; return; }
     (void)hipEventRecord(r.a, s);
     recs.push_back(r);
@@ -50,6 +50,20 @@ int KernelTimer::collect(int kind, int* launches, double* total_ms) {
     recs.swap(keep);
     if (launches) *launches = n;
     if (total_ms) *total_ms = ms;
+    return FDTD_OK;
+}
+int KernelTimer::timeline(int cap, int* kinds, int* parts, double* start_ms, double* dur_ms, int* n_out) {
+    if (n_out) *n_out = (int)recs.size();
+    for (size_t q = 0; q < recs.size() && (int)q < cap; ++q) {
+        FDTD_HIP(hipEventSynchronize(recs[q].b));
+        float t0 = 0, t1 = 0;
+        if (q > 0) FDTD_HIP(hipEventElapsedTime(&t0, recs[0].a, recs[q].a));
+        FDTD_HIP(hipEventElapsedTime(&t1, recs[q].a, recs[q].b));
+        if (kinds) kinds[q] = recs[q].kind;
+        if (parts) parts[q] = recs[q].part;
+        if (start_ms) start_ms[q] = t0;
+        if (dur_ms) dur_ms[q] = t1;
+    }
     return FDTD_OK;
 }
 void KernelTimer::release() {

@@ -217,13 +217,16 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // Per-launch HIP-event timing of the dominant kernels (optional, off by default).
 struct KernelTimer {
     bool enabled = false;
-    struct Rec { hipEvent_t a, b; int kind; };
+    struct Rec { hipEvent_t a, b; int kind, part; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
     hipEvent_t get();
-    void begin(int kind, hipStream_t s);
+    void begin(int kind, hipStream_t s, int part = 0);
     void end(hipStream_t s);
     int collect(int kind, int* launches, double* total_ms);
+    // every launch recorded since the last collect(), in launch order: kind, part, start relative to the
+    // first one's start and duration (ms); returns the number of launches (which may exceed `cap`)
+    int timeline(int cap, int* kinds, int* parts, double* start_ms, double* dur_ms, int* n_out);
     void release();
 };
 

@@ -160,7 +160,6 @@ __global__ void k_reduce(const T* arr, CompGeom g, double* sumsq_partial, unsign
     if (threadIdx.x == 0) { sumsq_partial[blockIdx.x] = sh[0]; atomicAdd(checksum, shc[0]); }
 }
 
-
 // Cell-centre observables (FDTD3D::run / dumpFrame, FDTD3D.cpp:1023-1097): every cell averages the
 // four Ex, Ey, Ez samples on its edges.  MODE 0: acc (+)= (1/16)(sx^2 + sy^2 + sz^2) * weight, the
 // running RMS window; MODE 1: out0 = (1/4) sx (centred Ex), out1 = ax^2 + ay^2 + az^2 (|E|^2).
@@ -215,6 +214,7 @@ struct fdtd3d_engine {
     virtual int reduce(int id, double* sumsq, uint64_t* checksum, hipStream_t s) = 0;
     virtual size_t device_bytes() = 0;
     virtual int tune(int chunk, int remap, int rows) = 0;
+    virtual void launch_shape(int out[6]) = 0;
     virtual int observe_accumulate(double weight, int reset, hipStream_t s) = 0;
     virtual int observe_rms(double* host, size_t n) = 0;
     virtual int observe_frame(double* ex_center, double* e_mag, size_t n, hipStream_t s) = 0;
@@ -235,6 +235,7 @@ struct Engine3 : fdtd3d_engine {
     T* alt[18] = {nullptr};           // fused stepping: the other D and B buffers of the ping-pong
     T* phE2[3][3][2];
     int wpbf = 16;                    // fused kernel: waves per workgroup (the last one is a halo row)
+    int edge_planes = 1;              // fused kernel on a slab: planes of the EDGE and of the TOP launch (FDTD_EDGE_PLANES)
     int fvec = VecWidth<T>::V;        // fused kernel: elements per lane (V or V/2)
     size_t plane = 0, fsize = 0, bytes = 0;
     T* fld[18] = {nullptr};           // D E B H eps mu, three each (mu only if has_mu; E,H absent in LEAN)
@@ -402,6 +403,7 @@ struct Engine3 : fdtd3d_engine {
             chunk = std::max(4, std::min(24, nzl / std::max(1, chunks_wanted)));
             if (per_chunk * ((nzl + chunk - 1) / chunk) < 1600) wpbf = 8;
         }
+        if (const char* e = getenv("FDTD_EDGE_PLANES")) { int c = atoi(e); if (c >= 1 && c <= 64) edge_planes = c; }
         if (const char* e = getenv("FDTD_Z_CHUNK")) { int c = atoi(e); if (c >= 1 && c <= 4096) chunk = c; }
         if (const char* e = getenv("FDTD_XCD_REMAP")) { int v = atoi(e); if (v >= 0 && v <= 65536) remap = v; }
         if (const char* e = getenv("FDTD_ROWS_PER_GROUP")) { int w = atoi(e); if (w >= 1 && w <= 4) wpb = w; }
@@ -458,6 +460,17 @@ struct Engine3 : fdtd3d_engine {
         if (w >= 1 && w <= 4) wpb = w;
         if (fused && w >= 2 && w <= 16) wpbf = w;
         return FDTD_OK;
+    }
+
+    // what the step kernels are launched with: planes per workgroup, rows per workgroup, tile order,
+    // elements per lane, planes of the EDGE/TOP launches, row pitch
+    void launch_shape(int out[6]) override {
+        out[0] = chunk;
+        out[1] = fused ? wpbf : wpb;
+        out[2] = remap == kRemapAuto ? (fused ? std::max(2, px / (kLanes * fvec)) : (full ? 4 : 1) * std::max(2, px / (kLanes * V))) : remap;
+        out[3] = fused ? fvec : V;
+        out[4] = edge_planes;
+        out[5] = px;
     }
 
     // ---- canonical <-> device index maps ------------------------------------------------
@@ -822,24 +835,24 @@ struct Engine3 : fdtd3d_engine {
         return false;
     }
     template <typename Kern>
-    int launch(Kern kern, K3<T> a, int kl0, int kl1, int kind, hipStream_t s) {
+    int launch(Kern kern, K3<T> a, int kl0, int kl1, int kind, hipStream_t s, int part = 0) {
         if (kl1 <= kl0) return FDTD_OK;
         a.kl0 = kl0; a.kl1 = kl1;
         a.nbz = (kl1 - kl0 + a.chunk - 1) / a.chunk;
         const unsigned nblk = (unsigned)a.nbx * a.nby * a.nbz;
-        timer.begin(kind, s);
+        timer.begin(kind, s, part);
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(kLanes * wpb), 0, s, a);
         timer.end(s);
         FDTD_HIP(hipGetLastError());
         return FDTD_OK;
     }
-    int launch_e(const K3<T>& a, int kl0, int kl1, hipStream_t s) {
-        if (full) return d.has_mu ? launch(k3_half_e<T, true, false>, a, kl0, kl1, 0, s) : launch(k3_half_e<T, false, false>, a, kl0, kl1, 0, s);
-        return d.has_mu ? launch(k3_half_e<T, true, true>, a, kl0, kl1, 0, s) : launch(k3_half_e<T, false, true>, a, kl0, kl1, 0, s);
+    int launch_e(const K3<T>& a, int kl0, int kl1, hipStream_t s, int part = 0) {
+        if (full) return d.has_mu ? launch(k3_half_e<T, true, false>, a, kl0, kl1, 0, s, part) : launch(k3_half_e<T, false, false>, a, kl0, kl1, 0, s, part);
+        return d.has_mu ? launch(k3_half_e<T, true, true>, a, kl0, kl1, 0, s, part) : launch(k3_half_e<T, false, true>, a, kl0, kl1, 0, s, part);
     }
-    int launch_h(const K3<T>& a, int kl0, int kl1, hipStream_t s) {
-        if (full) return d.has_mu ? launch(k3_half_h<T, true, false>, a, kl0, kl1, 1, s) : launch(k3_half_h<T, false, false>, a, kl0, kl1, 1, s);
-        return d.has_mu ? launch(k3_half_h<T, true, true>, a, kl0, kl1, 1, s) : launch(k3_half_h<T, false, true>, a, kl0, kl1, 1, s);
+    int launch_h(const K3<T>& a, int kl0, int kl1, hipStream_t s, int part = 0) {
+        if (full) return d.has_mu ? launch(k3_half_h<T, true, false>, a, kl0, kl1, 1, s, part) : launch(k3_half_h<T, false, false>, a, kl0, kl1, 1, s, part);
+        return d.has_mu ? launch(k3_half_h<T, true, true>, a, kl0, kl1, 1, s, part) : launch(k3_half_h<T, false, true>, a, kl0, kl1, 1, s, part);
     }
     int half_e(int n, int part, hipStream_t s) override {
         K3<T> a = args();
@@ -847,19 +860,19 @@ struct Engine3 : fdtd3d_engine {
         a.jx = a.src_on ? a.dt * wf[n] : (T)0;      // product formed first, as FDTD3D.cpp:482
         int kl0, kl1;
         if (!part_range(true, part, kl0, kl1)) return fail(FDTD_ERR_ARG, "half_e: bad part %d", part);
-        return launch_e(a, kl0, kl1, s);
+        return launch_e(a, kl0, kl1, s, part);
     }
     int half_h(int part, hipStream_t s) override {
         K3<T> a = args();
         int kl0, kl1;
         if (part == FDTD3D_PART_INTERIOR) {
             // everything except the highest owned cell layer: the planes below it, and the closing plane above it
-            int rc = launch_h(a, 1, nzl, s);
+            int rc = launch_h(a, 1, nzl, s, part);
             if (rc || !last_rank) return rc;
-            return launch_h(a, nzl + 1, nzp, s);
+            return launch_h(a, nzl + 1, nzp, s, part);
         }
         if (!part_range(false, part, kl0, kl1)) return fail(FDTD_ERR_ARG, "half_h: bad part %d", part);
-        return launch_h(a, kl0, kl1, s);
+        return launch_h(a, kl0, kl1, s, part);
     }
 
     template <int FV>
@@ -894,9 +907,9 @@ struct Engine3 : fdtd3d_engine {
     }
     int fused_part(int n, int part, hipStream_t s) override {
         if (!fused) return fail(FDTD_ERR_STATE, "fused stepping needs an engine created with FDTD3D_MODE_FUSED");
-        // EDGE only has to produce layer z_lo early, TOP only the top layer: short chunks keep those poorly
-        // filled launches small
-        const int lo = 1, hi = last_rank ? nzp : nzp - 1, few = std::min(chunk, 8);
+        // EDGE only has to produce layer z_lo early, TOP only the top layer: these launches have too few
+        // workgroups to fill the chip, so they take as few planes as possible and leave the rest to INTERIOR
+        const int lo = 1, hi = last_rank ? nzp : nzp - 1, few = std::min(chunk, edge_planes);
         const int cut = std::min(lo + few, hi), cut2 = std::max(cut, hi - few);
         int kl0, kl1;
         if (part == FDTD3D_PART_ALL) { kl0 = lo; kl1 = hi; }
@@ -929,7 +942,7 @@ struct Engine3 : fdtd3d_engine {
         a.kl_stop = hi; a.copy_top = last_rank ? 0 : 1;
         a.nbz = (a.kl1 - a.kl0 + a.chunk - 1) / a.chunk;
         if (kl1 > kl0) {
-            timer.begin(2, s);
+            timer.begin(2, s, part);
             if (fvec == V) launch_fused<V>(a, s); else launch_fused<V / 2>(a, s);
             timer.end(s);
             FDTD_HIP(hipGetLastError());
@@ -1063,6 +1076,11 @@ int fdtd3d_halo_at(fdtd3d_handle h, int parity, int which, int comp, void** p, s
 int fdtd3d_sumsq(fdtd3d_handle h, int id, double* out, void* stream) { return entry(h, [&] { return h->reduce(id, out, nullptr, (hipStream_t)stream); }); }
 int fdtd3d_checksum(fdtd3d_handle h, int id, uint64_t* out, void* stream) { return entry(h, [&] { return h->reduce(id, nullptr, out, (hipStream_t)stream); }); }
 size_t fdtd3d_device_bytes(fdtd3d_handle h) { return h ? h->device_bytes() : 0; }
+int fdtd3d_launch_shape(fdtd3d_handle h, int out[6]) {
+    if (!h || !out) return fail(FDTD_ERR_ARG, "null argument");
+    h->launch_shape(out);
+    return FDTD_OK;
+}
 int fdtd3d_tune(fdtd3d_handle h, int chunk, int remap, int rows) { return entry(h, [&] { return h->tune(chunk, remap, rows); }); }
 int fdtd3d_observe_accumulate(fdtd3d_handle h, double weight, int reset, void* stream) { return entry(h, [&] { return h->observe_accumulate(weight, reset, (hipStream_t)stream); }); }
 int fdtd3d_observe_rms(fdtd3d_handle h, double* host, size_t n) { return entry(h, [&] { return h->observe_rms(host, n); }); }
@@ -1074,6 +1092,9 @@ int fdtd3d_kernel_timing(fdtd3d_handle h, int enable) {
 }
 int fdtd3d_kernel_time(fdtd3d_handle h, int kind, int* launches, double* total_ms) {
     return entry(h, [&] { return h->timer.collect(kind, launches, total_ms); });
+}
+int fdtd3d_kernel_timeline(fdtd3d_handle h, int cap, int* kinds, int* parts, double* start_ms, double* dur_ms, int* n_launches) {
+    return entry(h, [&] { return h->timer.timeline(cap, kinds, parts, start_ms, dur_ms, n_launches); });
 }
 
 }  // extern "C"

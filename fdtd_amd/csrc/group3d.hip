@@ -5,7 +5,9 @@
 // spread over the GPUs of one node, for callers that do not want one process per GPU.
 #include "common.hpp"
 
+#include <cstdlib>
 #include <memory>
+#include <utility>
 
 using namespace fdtd;
 
@@ -18,9 +20,24 @@ struct fdtd3d_group {
     // above (up) and below (down); all blocking streams, so that calls on a member's device through
     // the null stream (downloads, observables) order themselves behind the step
     std::vector<hipStream_t> run, up, down;
-    // per member: lowest planes done (also: low ghost consumed), top layer done (also: high ghost
-    // consumed), D/E ghost from above arrived, B/H ghost from below arrived
-    std::vector<hipEvent_t> edge_done, top_done, hi_here, lo_here;
+    // Events.  HIP only records an event on a stream of the device the event was created on (waiting
+    // on it from another device's stream is fine), so every event belongs to the slab whose stream
+    // RECORDS it -- all four of slab r live on device[r]:
+    //   edge_done[r]  on run[r]:  lowest planes done (also: r's low ghost has been consumed)
+    //   top_done[r]   on run[r]:  top layer done (also: r's high ghost has been consumed)
+    //   sent_down[r]  on down[r]: r's lowest D/E planes have arrived in the high ghost of slab r-1
+    //   sent_up[r]    on up[r]:   r's top B/H planes have arrived in the low ghost of slab r+1
+    // Slab r-1 waits for sent_down[r], slab r+1 for sent_up[r].
+    std::vector<hipEvent_t> edge_done, top_done, sent_down, sent_up;
+    // The slab every stream and event was created for, so that record() can refuse a pair that would
+    // sit on different devices on a multi-GPU node -- also when all slabs share one device, where HIP
+    // itself would accept it.
+    std::vector<std::pair<void*, int>> owner;
+    long records_checked = 0;
+    int owner_of(void* handle) const {
+        for (const auto& o : owner) if (o.first == handle) return o.second;
+        return -1;
+    }
 
     ~fdtd3d_group() {
         for (size_t r = 0; r < member.size(); ++r) {
@@ -30,13 +47,24 @@ struct fdtd3d_group {
         for (size_t r = 0; r < member.size(); ++r) {
             DeviceScope scope(device[r]);
             for (auto* v : {&run, &up, &down}) if (r < v->size() && (*v)[r]) (void)hipStreamDestroy((*v)[r]);
-            for (auto* v : {&edge_done, &top_done, &hi_here, &lo_here}) if (r < v->size() && (*v)[r]) (void)hipEventDestroy((*v)[r]);
+            for (auto* v : {&edge_done, &top_done, &sent_down, &sent_up}) if (r < v->size() && (*v)[r]) (void)hipEventDestroy((*v)[r]);
             if (member[r]) fdtd3d_destroy(member[r]);
         }
     }
 };
 
 namespace {
+
+// hipEventRecord with the ownership rule enforced: event and stream must have been created for the
+// same slab (hence on the same device).
+int record(fdtd3d_group* g, hipEvent_t ev, hipStream_t stream) {
+    const int eo = g->owner_of((void*)ev), so = g->owner_of((void*)stream);
+    ++g->records_checked;
+    if (eo < 0 || eo != so)
+        return fail(FDTD_ERR_STATE, "group: event of slab %d recorded on a stream of slab %d (an event must be recorded on its own device)", eo, so);
+    FDTD_HIP(hipEventRecord(ev, stream));
+    return FDTD_OK;
+}
 
 // One x-y plane pair (components 0 and 1) from `src`'s send planes into `dst`'s ghost planes, on
 // `stream` (a stream of the source's device, which must be current).
@@ -62,9 +90,9 @@ int step_fused(fdtd3d_group* g, int n) {
     int rc;
     for (int r = 0; r < R; ++r) {
         DeviceScope scope(g->device[r]);
-        if (r > 0) FDTD_HIP(hipStreamWaitEvent(g->run[r], g->lo_here[r], 0));
+        if (r > 0) FDTD_HIP(hipStreamWaitEvent(g->run[r], g->sent_up[r - 1], 0));
         if ((rc = fdtd3d_fused(g->member[r], n, FDTD3D_PART_EDGE, g->run[r]))) return rc;
-        FDTD_HIP(hipEventRecord(g->edge_done[r], g->run[r]));
+        if ((rc = record(g, g->edge_done[r], g->run[r]))) return rc;
     }
     const int parity = fdtd3d_buffer_parity(g->member[0]);       // all members change buffers together
     for (int r = 1; r < R; ++r) {
@@ -72,21 +100,21 @@ int step_fused(fdtd3d_group* g, int n) {
         FDTD_HIP(hipStreamWaitEvent(g->down[r], g->edge_done[r], 0));
         FDTD_HIP(hipStreamWaitEvent(g->down[r], g->top_done[r - 1], 0));     // the ghost's previous content has been used
         if ((rc = copy_planes(g, r, FDTD3D_HALO_SEND_DOWN, r - 1, FDTD3D_HALO_RECV_HI, parity, g->down[r]))) return rc;
-        FDTD_HIP(hipEventRecord(g->hi_here[r - 1], g->down[r]));
+        if ((rc = record(g, g->sent_down[r], g->down[r]))) return rc;
     }
     for (int r = 0; r < R; ++r) {
         DeviceScope scope(g->device[r]);
         if ((rc = fdtd3d_fused(g->member[r], n, FDTD3D_PART_TOP, g->run[r]))) return rc;
-        if (r + 1 < R) FDTD_HIP(hipStreamWaitEvent(g->run[r], g->hi_here[r], 0));
+        if (r + 1 < R) FDTD_HIP(hipStreamWaitEvent(g->run[r], g->sent_down[r + 1], 0));
         if ((rc = fdtd3d_fused_top(g->member[r], g->run[r]))) return rc;
-        FDTD_HIP(hipEventRecord(g->top_done[r], g->run[r]));
+        if ((rc = record(g, g->top_done[r], g->run[r]))) return rc;
     }
     for (int r = 0; r + 1 < R; ++r) {
         DeviceScope scope(g->device[r]);
         FDTD_HIP(hipStreamWaitEvent(g->up[r], g->top_done[r], 0));
         FDTD_HIP(hipStreamWaitEvent(g->up[r], g->edge_done[r + 1], 0));      // the ghost's previous content has been used
         if ((rc = copy_planes(g, r, FDTD3D_HALO_SEND_UP, r + 1, FDTD3D_HALO_RECV_LO, parity, g->up[r]))) return rc;
-        FDTD_HIP(hipEventRecord(g->lo_here[r + 1], g->up[r]));
+        if ((rc = record(g, g->sent_up[r], g->up[r]))) return rc;
     }
     for (int r = 0; r < R; ++r) {
         DeviceScope scope(g->device[r]);
@@ -104,30 +132,30 @@ int step_halves(fdtd3d_group* g, int n) {
     for (int r = 0; r < R; ++r) {
         DeviceScope scope(g->device[r]);
         if ((rc = fdtd3d_half_e(g->member[r], n, FDTD3D_PART_INTERIOR, g->run[r]))) return rc;
-        if (r > 0) FDTD_HIP(hipStreamWaitEvent(g->run[r], g->lo_here[r], 0));
+        if (r > 0) FDTD_HIP(hipStreamWaitEvent(g->run[r], g->sent_up[r - 1], 0));
         if ((rc = fdtd3d_half_e(g->member[r], n, FDTD3D_PART_EDGE, g->run[r]))) return rc;
-        FDTD_HIP(hipEventRecord(g->edge_done[r], g->run[r]));
+        if ((rc = record(g, g->edge_done[r], g->run[r]))) return rc;
     }
     for (int r = 1; r < R; ++r) {
         DeviceScope scope(g->device[r]);
         FDTD_HIP(hipStreamWaitEvent(g->down[r], g->edge_done[r], 0));
         FDTD_HIP(hipStreamWaitEvent(g->down[r], g->top_done[r - 1], 0));
         if ((rc = copy_planes(g, r, FDTD3D_HALO_SEND_DOWN, r - 1, FDTD3D_HALO_RECV_HI, 0, g->down[r]))) return rc;
-        FDTD_HIP(hipEventRecord(g->hi_here[r - 1], g->down[r]));
+        if ((rc = record(g, g->sent_down[r], g->down[r]))) return rc;
     }
     for (int r = 0; r < R; ++r) {
         DeviceScope scope(g->device[r]);
         if ((rc = fdtd3d_half_h(g->member[r], FDTD3D_PART_INTERIOR, g->run[r]))) return rc;
-        if (r + 1 < R) FDTD_HIP(hipStreamWaitEvent(g->run[r], g->hi_here[r], 0));
+        if (r + 1 < R) FDTD_HIP(hipStreamWaitEvent(g->run[r], g->sent_down[r + 1], 0));
         if ((rc = fdtd3d_half_h(g->member[r], FDTD3D_PART_EDGE, g->run[r]))) return rc;
-        FDTD_HIP(hipEventRecord(g->top_done[r], g->run[r]));
+        if ((rc = record(g, g->top_done[r], g->run[r]))) return rc;
     }
     for (int r = 0; r + 1 < R; ++r) {
         DeviceScope scope(g->device[r]);
         FDTD_HIP(hipStreamWaitEvent(g->up[r], g->top_done[r], 0));
         FDTD_HIP(hipStreamWaitEvent(g->up[r], g->edge_done[r + 1], 0));
         if ((rc = copy_planes(g, r, FDTD3D_HALO_SEND_UP, r + 1, FDTD3D_HALO_RECV_LO, 0, g->up[r]))) return rc;
-        FDTD_HIP(hipEventRecord(g->lo_here[r + 1], g->up[r]));
+        if ((rc = record(g, g->sent_up[r], g->up[r]))) return rc;
     }
     for (int r = 0; r < R; ++r) {
         DeviceScope scope(g->device[r]);
@@ -171,11 +199,24 @@ int build_group(fdtd3d_group* g, const fdtd3d_desc* desc, int n_slabs, const int
     }
     const size_t R = (size_t)n_slabs;
     g->run.assign(R, nullptr); g->up.assign(R, nullptr); g->down.assign(R, nullptr);
-    g->edge_done.assign(R, nullptr); g->top_done.assign(R, nullptr); g->hi_here.assign(R, nullptr); g->lo_here.assign(R, nullptr);
+    g->edge_done.assign(R, nullptr); g->top_done.assign(R, nullptr); g->sent_down.assign(R, nullptr); g->sent_up.assign(R, nullptr);
+    // FDTD_GROUP_MISOWN_EVENTS=1 (tests only) files the two arrival events under the RECEIVING slab, the
+    // mistake the ownership rule exists to catch: the first step of such a group must be refused.
+    const char* mis = getenv("FDTD_GROUP_MISOWN_EVENTS");
+    const bool misown = mis && mis[0] == '1';
     for (size_t r = 0; r < R; ++r) {
         DeviceScope scope(g->device[r]);
-        for (auto* v : {&g->run, &g->up, &g->down}) FDTD_HIP(hipStreamCreate(&(*v)[r]));
-        for (auto* v : {&g->edge_done, &g->top_done, &g->hi_here, &g->lo_here}) FDTD_HIP(hipEventCreateWithFlags(&(*v)[r], hipEventDisableTiming));
+        for (auto* v : {&g->run, &g->up, &g->down}) {
+            FDTD_HIP(hipStreamCreate(&(*v)[r]));
+            g->owner.emplace_back((void*)(*v)[r], (int)r);
+        }
+        for (auto* v : {&g->edge_done, &g->top_done, &g->sent_down, &g->sent_up}) {
+            FDTD_HIP(hipEventCreateWithFlags(&(*v)[r], hipEventDisableTiming));
+            int own = (int)r;
+            if (misown && v == &g->sent_down && r > 0) own = (int)r - 1;
+            if (misown && v == &g->sent_up && r + 1 < R) own = (int)r + 1;
+            g->owner.emplace_back((void*)(*v)[r], own);
+        }
     }
     return FDTD_OK;
 }
@@ -215,6 +256,7 @@ int fdtd3d_group_destroy(fdtd3d_group_handle g) {
 }
 
 int fdtd3d_group_slabs(fdtd3d_group_handle g) { return g ? (int)g->member.size() : 0; }
+long fdtd3d_group_records_checked(fdtd3d_group_handle g) { return g ? g->records_checked : 0; }
 
 fdtd3d_handle fdtd3d_group_member(fdtd3d_group_handle g, int r) {
     return (g && r >= 0 && r < (int)g->member.size()) ? g->member[r] : nullptr;

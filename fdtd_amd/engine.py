@@ -34,6 +34,17 @@ D2_C1, D2_C2, D2_C3 = 21, 22, 23
 D2_PHI, D2_TAB, D2_JY = 100, 300, 400
 
 
+def kernel_source_digest() -> str:
+    """sha256 over the kernel sources the library was built from, so that a measurement taken on one build
+    (HBM traffic from a profiler pass) is not quoted next to timings of another."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("common.hpp", "kernels3d.hpp", "kernels3d_fused.hpp", "kernels2d.hpp", "kernels2d_fused.hpp"):
+        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 class EngineError(RuntimeError):
     pass
 
@@ -203,6 +214,18 @@ class Engine3D(_Common):
         n = lib().fdtd3d_placement_probes(self.h, buf, C.c_int(16))
         return [buf[i] for i in range(min(n, 16))]
 
+    def kernel_timeline(self):
+        """[(kind, part, start_ms, duration_ms)] of the launches timed since the last kernel_time() of their kind."""
+        n = C.c_int(0)
+        _check(lib().fdtd3d_kernel_timeline(self.h, C.c_int(0), None, None, None, None, C.byref(n)), "kernel_timeline")
+        cap = n.value
+        if cap == 0:
+            return []
+        kinds, parts = (C.c_int * cap)(), (C.c_int * cap)()
+        t0, dur = (C.c_double * cap)(), (C.c_double * cap)()
+        _check(lib().fdtd3d_kernel_timeline(self.h, C.c_int(cap), kinds, parts, t0, dur, C.byref(n)), "kernel_timeline")
+        return [(kinds[q], parts[q], t0[q], dur[q]) for q in range(min(cap, n.value))]
+
     def parity(self) -> int:
         """Which of the two D/B buffer sets is current (changes with every fused step)."""
         return lib().fdtd3d_buffer_parity(self.h)
@@ -246,6 +269,12 @@ class Engine3D(_Common):
 
     def tune(self, chunk: int = 0, remap: int = -1, rows: int = 0) -> None:
         _check(lib().fdtd3d_tune(self.h, C.c_int(chunk), C.c_int(remap), C.c_int(rows)), "fdtd3d_tune")
+
+    def launch_shape(self) -> dict:
+        """Launch shape of the step kernels in effect (fdtd3d_launch_shape)."""
+        o = (C.c_int * 6)()
+        _check(lib().fdtd3d_launch_shape(self.h, o), "fdtd3d_launch_shape")
+        return dict(zip(("planes_per_group", "rows_per_group", "xcd_run", "elements_per_lane", "edge_planes", "row_pitch"), list(o)))
 
     def checksum(self, id_: int, stream=None) -> int:
         v = C.c_uint64(0)

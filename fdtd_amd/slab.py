@@ -17,9 +17,15 @@ ghost plane; the wait sits in front of the one edge kernel that needs it.
 """
 from __future__ import annotations
 
+import time
 from typing import List, Sequence, Tuple
 
 PART_ALL, PART_EDGE, PART_INTERIOR, PART_TOP = 0, 1, 2, 3
+
+# Host time this process has spent inside HaloExchange.wait() and the number of waits that had something to
+# wait for.  With RCCL a wait only makes the launch stream wait (the device-side idle time shows up in the
+# engine's launch timeline instead); with a host-staged backend it is the real blocking time.
+WAIT_CLOCK = {"seconds": 0.0, "calls": 0}
 
 
 def partition(Nz: int, world: int) -> List[Tuple[int, int]]:
@@ -71,8 +77,13 @@ class HaloExchange:
 
     @staticmethod
     def wait(reqs) -> None:
+        if not reqs:
+            return
+        t0 = time.perf_counter()
         for r in reqs:
             r.wait()
+        WAIT_CLOCK["seconds"] += time.perf_counter() - t0
+        WAIT_CLOCK["calls"] += 1
 
 
 class _StagedSend:

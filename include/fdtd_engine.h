@@ -141,8 +141,8 @@ int fdtd3d_half_h(fdtd3d_handle h, int part, void* stream);
  * cell for cell in the same operation order), reading the current D, B and D-side CPML buffers
  * and writing the other set; the two sets change roles when the first part of a step is launched.
  *   PART_ALL       the whole slab.
- *   PART_EDGE      the lowest planes (at most 8), so that D of layer z_lo can travel down early.
- *   PART_TOP       optional, after EDGE: the highest planes (at most 8), so that the top layer can be
+ *   PART_EDGE      the lowest plane (FDTD_EDGE_PLANES in the environment: more), so that D of layer z_lo can travel down early.
+ *   PART_TOP       optional, after EDGE: the highest plane (or planes, likewise), so that the top layer can be
  *                  finished (fdtd3d_fused_top) and its B sent up while the bulk is still running.
  *   PART_INTERIOR  everything the step's earlier parts left; ends the step.
  * A slab below another one leaves B of its top layer z_hi-1 unchanged: once the upper
@@ -219,12 +219,22 @@ size_t fdtd3d_device_bytes(fdtd3d_handle h);
  * set them at creation; FDTD_FUSED_VEC (elements per lane of the fused kernel: 4 or 2 in fp32, 2 or 1
  * in fp64) can only be chosen there. */
 int fdtd3d_tune(fdtd3d_handle h, int chunk, int remap, int rows);
+/* The launch shape in effect: out = { planes per workgroup, rows per workgroup, tile order (runs of that
+ * many tiles per XCD; 0 as dealt, 1 contiguous), elements per lane, planes of the EDGE / TOP launches of
+ * a fused slab step, row pitch in elements }.  Measurements record it next to their numbers. */
+int fdtd3d_launch_shape(fdtd3d_handle h, int out[6]);
 
 /* Timing hook for the dominant kernels: if enabled, every E-half / H-half launch is
  * bracketed by HIP events on its stream; fdtd3d_kernel_time() synchronises and returns
  * the launch count and the summed device time (ms) per kernel kind (0 = E, 1 = H, 2 = fused). */
 int fdtd3d_kernel_timing(fdtd3d_handle h, int enable);
 int fdtd3d_kernel_time(fdtd3d_handle h, int kind, int* launches, double* total_ms);
+/* The launches timed since the last fdtd3d_kernel_time() call of their kind, in launch order: kind as
+ * above, the FDTD3D_PART_* the launch covered, its start relative to the first launch's start and its
+ * duration (ms).  The gap between one launch's end and the next one's start on the same stream is the
+ * time the stream waited (for a ghost plane, on a slab).  At most `cap` entries are written;
+ * *n_launches receives how many there are.  Synchronises; leaves the records in place. */
+int fdtd3d_kernel_timeline(fdtd3d_handle h, int cap, int* kinds, int* parts, double* start_ms, double* dur_ms, int* n_launches);
 
 /* ---- Several slabs driven from one host thread ------------------------------------------
  * FDTD3D::run() steps its whole grid from one thread (FDTD3D.cpp:1062-1111).  A group is that
@@ -243,6 +253,11 @@ typedef struct fdtd3d_group* fdtd3d_group_handle;
 int fdtd3d_group_create(const fdtd3d_desc* desc, int n_slabs, const int* devices, fdtd3d_group_handle* out);
 int fdtd3d_group_destroy(fdtd3d_group_handle g);
 int fdtd3d_group_slabs(fdtd3d_group_handle g);
+/* Every event of a group is recorded through a check that event and stream were created for the same
+ * slab (HIP refuses to record an event on a stream of another device; with all slabs on one device
+ * it would not notice).  A mismatch makes fdtd3d_group_step() fail with FDTD_ERR_STATE; this returns
+ * how many records have passed the check so far. */
+long fdtd3d_group_records_checked(fdtd3d_group_handle g);
 fdtd3d_handle fdtd3d_group_member(fdtd3d_group_handle g, int r);
 int fdtd3d_group_step(fdtd3d_group_handle g, int n0, int count);
 int fdtd3d_group_sync(fdtd3d_group_handle g);

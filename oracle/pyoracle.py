@@ -153,6 +153,10 @@ class _Base:
         if a.size and self._f("set")(self.h, C.c_int(id_), _ptr(a), C.c_size_t(a.size)):
             raise RuntimeError(f"set({id_}) failed")
 
+    def peek(self, id_: int, flat: int) -> float:
+        """One entry of a field array by flat canonical index (compiled reference only)."""
+        return self._f("peek", C.c_double)(self.h, C.c_int(id_), C.c_size_t(flat))
+
     def step(self, n0: int, count: int = 1) -> None:
         self._f("step", None)(self.h, C.c_int(n0), C.c_int(count))
 

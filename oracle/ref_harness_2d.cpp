@@ -113,6 +113,11 @@ size_t ref2d_size(void* h, int id) {
     if (id >= FDTD2D_TAB && id < FDTD2D_TAB + 24) { int r = id - FDTD2D_TAB; return layers(s, r / 12, (r / 6) % 2); }
     return 0;
 }
+// One entry of a field array (flat index in the reference's own order), for per-step probe series.
+double ref2d_peek(void* h, int id, size_t flat) {
+    auto* v = field((FDTD2D*)h, id);
+    return (v && flat < v->size()) ? (*v)[flat] : 0.0;
+}
 int ref2d_get(void* h, int id, double* dst, size_t n) {
     FDTD2D* s = (FDTD2D*)h;
     if (ref2d_size(h, id) != n) return 1;

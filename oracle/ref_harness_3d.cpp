@@ -179,6 +179,12 @@ int ref3d_get(void* h, int id, double* dst, size_t n) {
     return 1;
 }
 
+// One entry of a field array (flat index in the reference's own order), for per-step probe series.
+double ref3d_peek(void* h, int id, size_t flat) {
+    auto* v = field(((Ref3*)h)->s, id);
+    return (v && flat < v->size()) ? (*v)[flat] : 0.0;
+}
+
 int ref3d_set(void* h, int id, const double* src, size_t n) {
     FDTD3D* s = ((Ref3*)h)->s;
     if (ref3d_size(h, id) != n) return 1;

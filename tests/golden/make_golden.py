@@ -223,7 +223,100 @@ def g6():
     print(ka)
 
 
+def checksum(a) -> int:
+    """The engine's order-independent checksum (fdtd3d_checksum) of a float64 array in canonical order:
+    value bits mixed with the flat canonical index, summed modulo 2^64 over the non-zero entries."""
+    v = np.ascontiguousarray(a, dtype=np.float64).ravel()
+    idx = np.flatnonzero(v != 0.0).astype(np.uint64)
+    bits = v[idx.astype(np.int64)].view(np.uint64)
+    with np.errstate(over="ignore"):
+        z = bits + np.uint64(0x9E3779B97F4A7C15) * (idx + np.uint64(0x632BE59BD9B4E019))
+        for _ in range(2):
+            z = (z ^ (z >> np.uint64(32))) * np.uint64(0xD6E8FEB86659FD93)
+        z = z ^ (z >> np.uint64(32))
+        return int(z.sum(dtype=np.uint64))
+
+
+def g9():
+    """The UNMODIFIED 3-D default (200^3, 20-layer CPML, glass with an air sphere, Gaussian sheet source)
+    over its full run length of 1501 steps (FDTD3D.cpp:39): probe series at six cells for every step;
+    at steps 200, 750 and 1501 every 8th cell of all E and H components, the left-to-right sums of
+    squares and the engine-style checksums of all twelve field arrays."""
+    r = po.Ref3D()
+    s = r.scalars()
+    N, steps, npml = r.N, s["steps"], (20,) * 6
+    assert N == (200, 200, 200) and steps == 1501
+    ins = {}
+    for a in range(3):
+        for sd in range(2):
+            for k in range(6):
+                ins[po.tab_id(a, sd, k)] = r.get(po.tab_id(a, sd, k))
+    ins[po.JX_MAG] = r.get(po.JX_MAG)
+    ins[po.JX_WF] = r.get(po.JX_WF)
+    eps_sums = {str(po.EPS_X + c): checksum(r.get(po.EPS_X + c)) for c in range(3)}    # eps itself is regenerated on the device
+    probes = [(po.EX, (100, 100, 30)), (po.EX, (100, 100, 100)), (po.EY, (120, 80, 140)), (po.EZ, (90, 110, 60)),
+              (po.HY, (100, 100, 170)), (po.EX, (10, 190, 185))]
+    flat = []
+    for id_, cell in probes:
+        sh = po.shape3d(id_, N, npml)
+        flat.append(int(np.ravel_multi_index(cell, sh)))
+    series = np.zeros((steps, len(probes)))
+    snaps = (200, 750, 1501)
+    outs, sums, cks = {}, {}, {}
+    ids = (po.EX, po.EY, po.EZ, po.HX, po.HY, po.HZ)
+    import time
+    t0 = time.time()
+    for n in range(steps):
+        r.step(n)
+        for q, (id_, _) in enumerate(probes):
+            series[n, q] = r.peek(id_, flat[q])
+        if n + 1 in snaps:
+            for id_ in po.FIELDS3D:
+                a = r.get(id_, po.shape3d(id_, N, npml))
+                sums[f"{n + 1}:{id_}"] = seq_sumsq(a)
+                cks[f"{n + 1}:{id_}"] = checksum(a)
+                if id_ in ids:
+                    outs[(n + 1, id_)] = a[::8, ::8, ::8].copy()
+            print(f"g9: step {n + 1} after {time.time() - t0:.0f} s", flush=True)
+    meta = dict(kind="3d", N=N, npml=npml, steps=steps, k_Jx=s["k_Jx"], snapshots=list(snaps), subsample=8,
+                probes=[[id_, list(cell)] for id_, cell in probes], sumsq=sums, checksums=cks, eps_checksums=eps_sums,
+                **{k: s[k] for k in ("dx", "dy", "dz", "dt", "mu0", "eps0")},
+                note="unmodified reference default problem over its full 1501 steps; eps is not stored (the engine "
+                     "regenerates it with fdtd3d_fill_reference_materials; its checksums are)")
+    save("g9_3d_default_full_run", meta, ins, outs, {"probe": series})
+
+
+def g10():
+    """The UNMODIFIED 2-D default (200x480, Lorentz slab, 20-layer CPML) over its full 1580 steps
+    (FDTD2D.cpp:38): probe series at five cells for every step; Ey, Hx, Hz, SEy in full at steps 400,
+    1000 and 1580."""
+    r = po.Ref2D()
+    s = r.scalars()
+    Nx, Nz, steps, npml = s["Nx"], s["Nz"], s["steps"], (20,) * 4
+    assert (Nx, Nz, steps) == (200, 480, 1580)
+    ins = inputs2d(r)
+    probes = [(po.D2_EY, (60, 240)), (po.D2_EY, (100, 240)), (po.D2_EY, (140, 240)), (po.D2_HX, (160, 240)), (po.D2_EY, (100, 30))]
+    flat = [int(np.ravel_multi_index(cell, po.shape2d(id_, Nx, Nz, npml))) for id_, cell in probes]
+    series = np.zeros((steps, len(probes)))
+    snaps = (400, 1000, 1580)
+    outs, sums = {}, {}
+    for n in range(steps):
+        r.step(n)
+        for q, (id_, _) in enumerate(probes):
+            series[n, q] = r.peek(id_, flat[q])
+        if n + 1 in snaps:
+            for id_ in (po.D2_EY, po.D2_HX, po.D2_HZ, po.D2_SEY, po.D2_DY):
+                a = r.get(id_)
+                outs[(n + 1, id_)] = a
+                sums[f"{n + 1}:{id_}"] = seq_sumsq(a)
+    meta = dict(kind="2d", Nx=Nx, Nz=Nz, npml=npml, steps=steps, i_Jy=s["i_Jy"], k_Jy=s["k_Jy"], snapshots=list(snaps),
+                probes=[[id_, list(cell)] for id_, cell in probes], sumsq=sums,
+                **{k: s[k] for k in ("dx", "dz", "dt", "mu0", "eps0")},
+                note="unmodified reference default problem over its full 1580 steps")
+    save("g10_2d_default_full_run", meta, ins, outs, {"probe": series})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for w in which:
         globals()[w]()

@@ -42,6 +42,34 @@ def test_two_and_three_ranks_equal_one(mode):
         assert many["checks"]["checksum_dx"] == one["checks"]["checksum_dx"]
         for key in ("metric", "value", "unit", "ms_per_step", "roofline", "scaling", "dtype", "config"):
             assert key in many
+        _check_multi_gpu_block(many, ranks, mode, "gloo")
+
+
+def _check_multi_gpu_block(line, ranks, mode, backend):
+    """What makes a first run on real peers diagnosable from the one line: who took part, and per rank where
+    its step went -- every kind of launch, the idle time of its stream in front of the launches that wait
+    for a ghost plane, host time spent waiting for exchanges."""
+    mg = line["multi_gpu"]
+    assert mg["world_size"] == ranks and backend in mg["backend"] and len(mg["per_rank"]) == ranks
+    roof = line["roofline"]
+    assert 0 < roof["frac"] and roof["kernel_ms_per_step"] > 0 and roof["traffic"] is None
+    assert roof["own_model_bytes_per_cell"] < roof["algorithmic_bytes_per_cell"] or mode == "full"
+    for r, rec in enumerate(mg["per_rank"]):
+        assert rec.get("rank", rec.get("slab")) == r and rec["device"] == 0
+        assert rec["layers"][1] > rec["layers"][0]
+        ms, n, idle = rec["launch_ms_per_step"], rec["launches_per_step"], rec["stream_idle_ms_per_step_before"]
+        if mode == "fused":
+            want = {"fused_edge", "fused_top", "fused_interior"} | ({"half_h_edge"} if r + 1 < ranks else set())
+        else:
+            want = {"half_e_interior", "half_e_edge", "half_h_interior", "half_h_edge"}
+        assert want <= set(ms), (r, sorted(ms))
+        assert all(ms[k] > 0 and n[k] >= 1 for k in want)
+        assert all(v >= 0 for v in idle.values())
+        assert abs(sum(ms.values()) - rec["kernel_ms_per_step"]) < 1e-6 * max(1.0, rec["kernel_ms_per_step"]) or mode != "fused"
+        assert rec["first_to_last_launch_ms_per_step"] >= sum(ms.values()) * 0.999
+    if "gloo" in backend:
+        # the host-staged rehearsal really blocks in the exchange waits
+        assert all(rec["host_wait_ms_per_step"] > 0 and rec["exchange_waits_per_step"] >= 1 for rec in mg["per_rank"])
 
 
 @pytest.mark.parametrize("mode", ["fused", "full"])
@@ -62,6 +90,7 @@ def test_single_process_group_mode_equals_one(mode):
     assert many["checks"]["checksum_dx"] == one["checks"]["checksum_dx"]
     for key in ("metric", "value", "unit", "ms_per_step", "roofline", "scaling", "dtype", "config"):
         assert key in many
+    _check_multi_gpu_block(many, 3, mode, "one host thread")
 
 
 def test_rccl_self_exchange_on_engine_memory():

@@ -133,10 +133,12 @@ def run_fused_slabs(meta, ins, parts, prec, steps, chunk, has_mu=False, extra_fe
 
 
 @pytest.mark.parametrize("use_top", [True, False])
-@pytest.mark.parametrize("name,world,chunk", [("g1_3d_cpml", 2, 8), ("g3_3d_hetero", 3, 2), ("g2_3d_cavity", 4, 3), ("g3_3d_hetero", 8, 16)])
-def test_fused_slabs_reproduce_reference(name, world, chunk, use_top):
+@pytest.mark.parametrize("name,world,chunk,edge_planes", [("g1_3d_cpml", 2, 8, 1), ("g3_3d_hetero", 3, 2, 2), ("g2_3d_cavity", 4, 3, 3),
+                                                          ("g3_3d_hetero", 8, 16, 1), ("g1_3d_cpml", 3, 16, 8)])
+def test_fused_slabs_reproduce_reference(name, world, chunk, edge_planes, use_top, monkeypatch):
     from fdtd_amd import slab
     from tests.test_gpu_slabs import assemble
+    monkeypatch.setenv("FDTD_EDGE_PLANES", str(edge_planes))     # planes of the EDGE and TOP launches, read at creation
     meta, ins, outs, _ = util.load_fixture(name)
     steps = meta["steps"]
     engs = run_fused_slabs(meta, ins, slab.partition(meta["N"][2], world), 64, steps, chunk, use_top=use_top)

@@ -158,3 +158,28 @@ def test_group_refusals():
     h = C.c_void_p()
     assert L.fdtd3d_group_create(C.byref(desc), 2, None, C.byref(h)) == 1 and b"whole grid" in L.fdtd_last_error()
     assert L.fdtd3d_group_step(None, 0, 1) == 1 and L.fdtd3d_group_slabs(None) == 0 and L.fdtd3d_group_destroy(None) == 0
+
+
+def test_group_events_are_recorded_on_streams_of_their_own_slab(monkeypatch):
+    """HIP refuses to record an event on a stream of another device.  With every slab on device 0 the
+    runtime cannot notice, so the group checks the pairing itself: each record of a step passes the
+    check, and a group whose arrival events are filed under the receiving slab (the layout that fails
+    between real devices) is refused at its first step."""
+    meta, ins, _, _ = util.load_fixture("g1_3d_cpml")
+    L = E.lib()
+    L.fdtd3d_group_records_checked.restype = C.c_long
+    for mode in (E.MODE_FUSED, E.MODE_LEAN):
+        g = group_from_meta(meta, 32, 3, mode)
+        util.feed(g, ins)
+        g.step(0, 2)
+        g.sync()
+        # per step: edge_done and top_done on each of 3 slabs, one arrival event per direction and interface
+        assert L.fdtd3d_group_records_checked(g.h) == 2 * (3 + 3 + 2 + 2)
+        g.close()
+    monkeypatch.setenv("FDTD_GROUP_MISOWN_EVENTS", "1")
+    for mode in (E.MODE_FUSED, E.MODE_LEAN):
+        g = group_from_meta(meta, 32, 3, mode)
+        util.feed(g, ins)
+        with pytest.raises(E.EngineError, match="recorded on a stream of slab"):
+            g.step(0, 1)
+        g.close()
