@@ -198,6 +198,7 @@ struct fdtd3d_engine {
     virtual int get_array(int id, double* host, size_t n) = 0;
     virtual int fill_materials(uint64_t seed, double elo, double ehi, double mlo, double mhi) = 0;
     virtual int fill_reference_materials() = 0;
+    virtual int fill_array(int id, uint64_t seed, double lo, double hi) = 0;
     virtual int half_e(int n, int part, hipStream_t s) = 0;
     virtual int half_h(int part, hipStream_t s) = 0;
     virtual int step(int n, hipStream_t s) = 0;
@@ -424,8 +425,35 @@ struct Engine3 : fdtd3d_engine {
         if (const char* e = getenv("FDTD_PLACEMENT_TRIES")) { int v = atoi(e); if (v >= 1 && v <= 16) tries = v; }
         int explore = 3;                 // placements timed before the first may be accepted
         if (const char* e = getenv("FDTD_PLACEMENT_EXPLORE")) { int v = atoi(e); if (v >= 1 && v <= 16) explore = v; }
+        // Experiment / alternative: FDTD_PLACEMENT_SCAN_MB="0,256,512" makes ONE allocation with room for the
+        // largest offset, times the arena at each offset inside it (no free + allocate in between) and keeps
+        // the fastest.
+        std::vector<size_t> scan;
+        if (const char* e = getenv("FDTD_PLACEMENT_SCAN_MB")) {
+            for (const char* q = e; *q;) { char* end = nullptr; const long v = strtol(q, &end, 10); if (end == q) break; if (v >= 0) scan.push_back((size_t)v << 20); q = *end ? end + 1 : end; }
+        }
+        if (!scan.empty()) {
+            const size_t slack = *std::max_element(scan.begin(), scan.end());
+            char* base = nullptr;
+            FDTD_HIP(hipMalloc((void**)&base, arena_cap + slack));
+            allocs.push_back(base);
+            size_t best_off = scan[0];
+            double best_ms = 1e300;
+            for (size_t off : scan) {
+                arena = base + off; arena_used = 0; bytes = 0;
+                if ((rc = allocate_all())) return rc;
+                double ms = 0;
+                if ((rc = probe(&ms))) return rc;
+                placement_log.push_back(ms);
+                if (getenv("FDTD_PLACEMENT_DEBUG")) fprintf(stderr, "[fdtd] arena at %p + %zu MB: %.3f ms/step\n", (void*)base, off >> 20, ms);
+                if (ms < best_ms) { best_ms = ms; best_off = off; }
+            }
+            arena = base + best_off; arena_used = 0; bytes = 0;
+            if ((rc = allocate_all())) return rc;
+            tries = 0;
+        }
         double best = 1e300, worst = 0;
-        for (int t = 0;; ++t) {
+        for (int t = 0; tries > 0; ++t) {
             arena_used = 0; bytes = 0;
             FDTD_HIP(hipMalloc((void**)&arena, arena_cap));
             allocs.push_back(arena);
@@ -729,6 +757,15 @@ struct Engine3 : fdtd3d_engine {
             hipLaunchKernelGGL(k_fill_hash<T>, dim3(2048), dim3(256), 0, 0, fld[12 + c], geom(12 + c, false), seed, (uint32_t)c, elo, ehi, 0, nzp);
             if (d.has_mu) hipLaunchKernelGGL(k_fill_hash<T>, dim3(2048), dim3(256), 0, 0, fld[15 + c], geom(15 + c, false), seed, (uint32_t)(3 + c), mlo, mhi, 0, nzp);
         }
+        FDTD_HIP(hipGetLastError());
+        FDTD_HIP(hipDeviceSynchronize());
+        return FDTD_OK;
+    }
+
+    // any resident field array filled with the counter hash (measurements on a state without zeros)
+    int fill_array(int id, uint64_t seed, double lo, double hi) override {
+        if (id < 0 || id >= 18 || !fld[id]) return fail(FDTD_ERR_ARG, "fill_array: array %d is not a resident field", id);
+        hipLaunchKernelGGL(k_fill_hash<T>, dim3(2048), dim3(256), 0, 0, fld[id], geom(id, false), seed, (uint32_t)(32 + id), lo, hi, 0, nzp);
         FDTD_HIP(hipGetLastError());
         FDTD_HIP(hipDeviceSynchronize());
         return FDTD_OK;
@@ -1045,6 +1082,7 @@ int fdtd3d_fill_materials(fdtd3d_handle h, uint64_t seed, double elo, double ehi
     return entry(h, [&] { return h->fill_materials(seed, elo, ehi, mlo, mhi); });
 }
 int fdtd3d_fill_reference_materials(fdtd3d_handle h) { return entry(h, [&] { return h->fill_reference_materials(); }); }
+int fdtd3d_fill_array(fdtd3d_handle h, int id, uint64_t seed, double lo, double hi) { return entry(h, [&] { return h->fill_array(id, seed, lo, hi); }); }
 int fdtd3d_step(fdtd3d_handle h, int n0, int count, void* stream) {
     return entry(h, [&]() -> int {
         if (h->d.z_lo != 0 || h->d.z_hi != h->d.Nz) return fail(FDTD_ERR_STATE, "fdtd3d_step needs the whole grid on this device; slab drivers use fdtd3d_half_e / fdtd3d_half_h or fdtd3d_fused");

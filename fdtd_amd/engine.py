@@ -238,6 +238,10 @@ class Engine3D(_Common):
         _check(lib().fdtd3d_fill_materials(self.h, C.c_uint64(seed), C.c_double(eps_lo), C.c_double(eps_hi),
                                            C.c_double(mu_lo), C.c_double(mu_hi)), "fdtd3d_fill_materials")
 
+    def fill_array(self, id_: int, seed: int, lo: float, hi: float) -> None:
+        """Counter-hash values in [lo, hi) into a resident field array (a state without zeros)."""
+        _check(lib().fdtd3d_fill_array(self.h, C.c_int(id_), C.c_uint64(seed), C.c_double(lo), C.c_double(hi)), "fdtd3d_fill_array")
+
     def fill_reference_materials(self) -> None:
         """The reference's default eps (glass with an air sphere) generated on the device."""
         _check(lib().fdtd3d_fill_reference_materials(self.h), "fdtd3d_fill_reference_materials")

@@ -117,6 +117,10 @@ int fdtd3d_get_array(fdtd3d_handle h, int id, double* host, size_t n);
 int fdtd3d_fill_materials(fdtd3d_handle h, uint64_t seed, double eps_lo, double eps_hi,
                           double mu_lo, double mu_hi);
 
+/* The same counter hash into any resident field array (ids 0..17), values in [lo, hi): a state without
+ * zeros for measurements (is the step time independent of the data?) and tests; ghost planes included. */
+int fdtd3d_fill_array(fdtd3d_handle h, int id, uint64_t seed, double lo, double hi);
+
 /* FDTD3D::setupMaterials (FDTD3D.cpp:106-200) evaluated on the device for the layers this engine
  * stores: fused silica (n = 1.47) with a centred air sphere of radius two wavelengths, 3 x 3
  * sub-sampled -- fp64, operation for operation as fdtd3d_default_materials() on the host (the two

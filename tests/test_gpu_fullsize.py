@@ -34,18 +34,19 @@ def make(N, npml, mode, has_mu, z_range=None, steps=64, dipole=False):
     return eng
 
 
-def test_vacuum_cavity_512_lean_equals_full_and_stays_bounded():
-    """512^3 vacuum cavity (no CPML), dipole source."""
-    N, steps = (512, 512, 512), 24
+def test_vacuum_cavity_512_all_modes_equal_and_stay_bounded():
+    """512^3 vacuum cavity (no CPML), dipole source: the default fused kernel, lean and full storage leave the
+    same bits in D and B (an odd step count, so that the fused engine is read from its second buffer set)."""
+    N, steps = (512, 512, 512), 25
     sums = {}
-    for mode in (E.MODE_FULL, E.MODE_LEAN):
+    for mode in (E.MODE_FULL, E.MODE_LEAN, E.MODE_FUSED):
         eng = make(N, (0,) * 6, mode, False, steps=steps, dipole=True)
         eng.step(0, steps)
         sums[mode] = [eng.checksum(i) for i in FIELDS]
         energy = [eng.sumsq(i) for i in FIELDS]
         assert all(np.isfinite(energy)) and energy[0] > 0
         eng.close()
-    assert sums[E.MODE_FULL] == sums[E.MODE_LEAN]
+    assert sums[E.MODE_FULL] == sums[E.MODE_LEAN] == sums[E.MODE_FUSED]
 
 
 def test_hetero_cpml_slabs_equal_whole_grid_384():

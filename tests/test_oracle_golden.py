@@ -162,3 +162,43 @@ def test_known_answers_on_reference_defaults():
         t3.set(po.EPS_X + c, e)
     t3.step(0, 5)
     assert util.seq_sumsq(t3.get(po.EX)) == ka["sumsq_ex_3d_default_5_steps"]
+
+
+def test_twin64_matches_reference_2d_default_over_its_full_run():
+    """The unmodified 2-D default over all 1580 steps (fixture g10): probe series of every step and
+    the snapshots, bit for bit."""
+    meta, ins, outs, extra = util.load_fixture("g10_2d_default_full_run")
+    tw = util.twin2d_from_meta(meta, 64)
+    util.feed(tw, ins)
+    cells = [(id_, po.shape2d(id_, meta["Nx"], meta["Nz"], meta["npml"]), tuple(c)) for id_, c in meta["probes"]]
+    series = np.zeros((meta["steps"], len(cells)))
+
+    def on_step(n):
+        for q, (id_, shp, c) in enumerate(cells):
+            series[n, q] = tw.get(id_, shp)[c]
+
+    got = util.run_snapshots(tw, meta, outs, on_step)
+    for key, want in outs.items():
+        util.assert_equal_arrays(got[key], want, f"g10 step {key[0]} array {key[1]}")
+    util.assert_equal_arrays(series, extra["probe"], "g10 probe series")
+
+
+def test_twin64_matches_reference_3d_default_first_200_steps():
+    """The unmodified 3-D default (fixture g9, 200^3): the first 200 of its 1501 steps on the CPU twin --
+    the whole run takes the twin several minutes; the GPU suite covers all 1501 steps.  eps comes from
+    the host restatement of setupMaterials and must carry the reference's checksums."""
+    from tests.golden.make_golden import checksum
+    meta, ins, outs, extra = util.load_fixture("g9_3d_default_full_run")
+    tw = util.twin3d_from_meta(meta, 64)
+    util.feed(tw, ins)
+    eps = po.default_materials3d(meta["N"], (meta["dx"], meta["dy"], meta["dz"]))
+    for c in range(3):
+        assert checksum(eps[c]) == meta["eps_checksums"][str(po.EPS_X + c)]
+        tw.set(po.EPS_X + c, eps[c])
+    snap, sub = 200, meta["subsample"]
+    tw.step(0, snap)
+    for id_ in po.FIELDS3D:
+        full = tw.get(id_, po.shape3d(id_, meta["N"], meta["npml"]))
+        assert checksum(full) == meta["checksums"][f"{snap}:{id_}"], f"g9 step {snap} array {id_}"
+        if (snap, id_) in outs:
+            util.assert_equal_arrays(full[::sub, ::sub, ::sub], outs[(snap, id_)], f"g9 step {snap} array {id_}")

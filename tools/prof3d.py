@@ -39,6 +39,10 @@ eng.set(fdtd_amd.engine.JX_MAG, mag)
 eng.fill_materials(1234, K["eps0"], 4 * K["eps0"], K["mu0"], 2 * K["mu0"])
 if args.chunk or args.rows:
     eng.tune(args.chunk, -1, args.rows)
+if os.environ.get("FDTD_SHAPE_OUT"):            # for tools/pmc_traffic.py: the launch shape these launches use
+    import json
+    with open(os.environ["FDTD_SHAPE_OUT"], "w") as f:
+        json.dump(eng.launch_shape(), f)
 eng.step(0, args.steps)
 torch.cuda.synchronize()
 print("done", args.mode, n, args.steps)
