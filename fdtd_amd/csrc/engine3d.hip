@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 
 namespace fdtd {
 
@@ -160,6 +161,29 @@ __global__ void k_reduce(const T* arr, CompGeom g, double* sumsq_partial, unsign
     if (threadIdx.x == 0) { sumsq_partial[blockIdx.x] = sh[0]; atomicAdd(checksum, shc[0]); }
 }
 
+// ---- fdtd3d_reduce_static: the reduction above without any allocation ------------------------------
+// Its partial sums live in this file-scope array instead of memory obtained from hipMalloc, so the
+// call can be made where allocating is not an option.  Every GPU the library runs on holds its own copy
+// of the array (at its own address) until the process ends; all calls on one GPU share that copy, so
+// calls that overlap on one GPU race.
+constexpr int kStaticMaxIds = 16;                     // arrays reduced by one call
+constexpr int kReduceBlocks = 1024;                   // workgroups of k_reduce = partial sums per array
+constexpr int kStaticSlot = kReduceBlocks + 1;        // per array: the partial sums, then the checksum word
+constexpr size_t kStaticDoubles = (size_t)kStaticMaxIds * kStaticSlot + 2 * kStaticMaxIds;   // + (sum, checksum) per array
+static __device__ __align__(256) double scratch[kStaticDoubles];       // 131,456 bytes
+
+// One thread per array: adds the partial sums in index order (the order the host loop of the allocating
+// entry point uses, so both give the same bits) and packs (sum, checksum bits) for one small download.
+__global__ void k_reduce_finish(const double* slots, double* results, int n_ids) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_ids) return;
+    const double* sl = slots + (size_t)q * kStaticSlot;
+    double acc = 0;
+    for (int b = 0; b < kReduceBlocks; ++b) acc += sl[b];
+    results[2 * q] = acc;
+    results[2 * q + 1] = sl[kReduceBlocks];
+}
+
 // Cell-centre observables (FDTD3D::run / dumpFrame, FDTD3D.cpp:1023-1097): every cell averages the
 // four Ex, Ey, Ez samples on its edges.  MODE 0: acc (+)= (1/16)(sx^2 + sy^2 + sz^2) * weight, the
 // running RMS window; MODE 1: out0 = (1/4) sx (centred Ex), out1 = ax^2 + ay^2 + az^2 (|E|^2).
@@ -191,6 +215,28 @@ __global__ void k3_observe(const K3<T> a, T* out0, T* out1, T weight, int reset,
 
 using namespace fdtd;
 
+// Address of `scratch` on device `dev`, which must be the calling thread's current device.  The name of a
+// __device__ array is only a stand-in on the host side; the memory behind it is found once per device
+// with hipGetSymbolAddress and that pointer is what kernels, memsets and copies are given.
+static int static_scratch(int dev, double** out) {
+    constexpr int kMaxDevices = 64;
+    static std::mutex mu;
+    static double* ptr[kMaxDevices] = {nullptr};
+    if (dev < 0 || dev >= kMaxDevices) return fail(FDTD_ERR_ARG, "reduce_static: device ordinal %d outside [0,%d)", dev, kMaxDevices);
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptr[dev]) {
+        int cur = -1;
+        FDTD_HIP(hipGetDevice(&cur));
+        if (cur != dev) return fail(FDTD_ERR_STATE, "reduce_static: device %d is current, the engine lives on %d", cur, dev);
+        void* p = nullptr;
+        FDTD_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(FDTD_ERR_HIP, "reduce_static: no address for the scratch array on device %d", dev);
+        ptr[dev] = static_cast<double*>(p);
+    }
+    *out = ptr[dev];
+    return FDTD_OK;
+}
+
 struct fdtd3d_engine {
     virtual ~fdtd3d_engine() {}
     virtual size_t array_size(int id) = 0;
@@ -213,6 +259,7 @@ struct fdtd3d_engine {
     virtual int probe_count() = 0;
     virtual int halo(int which, int comp, void** p, size_t* bytes, int at_parity) = 0;
     virtual int reduce(int id, double* sumsq, uint64_t* checksum, hipStream_t s) = 0;
+    virtual int reduce_static(const int* ids, int n_ids, double* sumsq, uint64_t* checksum, hipStream_t s) = 0;
     virtual size_t device_bytes() = 0;
     virtual int tune(int chunk, int remap, int rows) = 0;
     virtual void launch_shape(int out[6]) = 0;
@@ -787,7 +834,7 @@ struct Engine3 : fdtd3d_engine {
     int reduce(int id, double* sumsq, uint64_t* checksum, hipStream_t s) override {
         if (id < 0 || id >= 18 || !fld[id]) return fail(FDTD_ERR_ARG, "reduce: array %d is not a resident field", id);
         FDTD_HIP(hipMemsetAsync(red_d, 0, 1025 * sizeof(double), s));
-        hipLaunchKernelGGL(k_reduce<T>, dim3(1024), dim3(256), 0, s, fld[id], geom(id, true), red_d, (unsigned long long*)(red_d + 1024));
+        hipLaunchKernelGGL(k_reduce<T>, dim3(kReduceBlocks), dim3(256), 0, s, fld[id], geom(id, true), red_d, (unsigned long long*)(red_d + kReduceBlocks));
         FDTD_HIP(hipGetLastError());
         std::vector<double> h(1025);
         FDTD_HIP(hipMemcpyAsync(h.data(), red_d, 1025 * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -796,6 +843,35 @@ struct Engine3 : fdtd3d_engine {
         for (int q = 0; q < 1024; ++q) acc += h[q];
         if (sumsq) *sumsq = acc;
         if (checksum) std::memcpy(checksum, &h[1024], sizeof(uint64_t));
+        return FDTD_OK;
+    }
+
+    // The same reduction for up to kStaticMaxIds arrays in one call, with the partial sums in the file-scope
+    // scratch array: no hipMalloc, no hipFree, no host container.  One stream synchronisation at the end.
+    int reduce_static(const int* ids, int n_ids, double* sumsq, uint64_t* checksum, hipStream_t s) override {
+        if (n_ids < 0 || (n_ids > 0 && !ids)) return fail(FDTD_ERR_ARG, "reduce_static: bad id list");
+        if (n_ids > kStaticMaxIds) return fail(FDTD_ERR_ARG, "reduce_static: %d arrays asked for, the static scratch holds partial sums for at most %d", n_ids, kStaticMaxIds);
+        for (int q = 0; q < n_ids; ++q)
+            if (ids[q] < 0 || ids[q] >= 18 || !fld[ids[q]]) return fail(FDTD_ERR_ARG, "reduce_static: array %d is not a resident field", ids[q]);
+        if (n_ids == 0) return FDTD_OK;
+        double* sc = nullptr;
+        if (int rc = static_scratch(device, &sc)) return rc;
+        double* results = sc + (size_t)kStaticMaxIds * kStaticSlot;
+        // the array keeps what the previous call left: the checksum words are accumulated into, so they start at zero
+        FDTD_HIP(hipMemsetAsync(sc, 0, (size_t)n_ids * kStaticSlot * sizeof(double), s));
+        for (int q = 0; q < n_ids; ++q) {
+            double* slot = sc + (size_t)q * kStaticSlot;
+            hipLaunchKernelGGL(k_reduce<T>, dim3(kReduceBlocks), dim3(256), 0, s, fld[ids[q]], geom(ids[q], true), slot, (unsigned long long*)(slot + kReduceBlocks));
+        }
+        hipLaunchKernelGGL(k_reduce_finish, dim3(1), dim3(64), 0, s, sc, results, n_ids);
+        FDTD_HIP(hipGetLastError());
+        double host[2 * kStaticMaxIds];
+        FDTD_HIP(hipMemcpyAsync(host, results, (size_t)2 * n_ids * sizeof(double), hipMemcpyDeviceToHost, s));
+        FDTD_HIP(hipStreamSynchronize(s));
+        for (int q = 0; q < n_ids; ++q) {
+            if (sumsq) sumsq[q] = host[2 * q];
+            if (checksum) std::memcpy(&checksum[q], &host[2 * q + 1], sizeof(uint64_t));
+        }
         return FDTD_OK;
     }
 
@@ -1113,6 +1189,9 @@ int fdtd3d_halo_at(fdtd3d_handle h, int parity, int which, int comp, void** p, s
 }
 int fdtd3d_sumsq(fdtd3d_handle h, int id, double* out, void* stream) { return entry(h, [&] { return h->reduce(id, out, nullptr, (hipStream_t)stream); }); }
 int fdtd3d_checksum(fdtd3d_handle h, int id, uint64_t* out, void* stream) { return entry(h, [&] { return h->reduce(id, nullptr, out, (hipStream_t)stream); }); }
+int fdtd3d_reduce_static(fdtd3d_handle h, const int* ids, int n_ids, double* sumsq, uint64_t* checksum, void* stream) {
+    return entry(h, [&] { return h->reduce_static(ids, n_ids, sumsq, checksum, (hipStream_t)stream); });
+}
 size_t fdtd3d_device_bytes(fdtd3d_handle h) { return h ? h->device_bytes() : 0; }
 int fdtd3d_launch_shape(fdtd3d_handle h, int out[6]) {
     if (!h || !out) return fail(FDTD_ERR_ARG, "null argument");

@@ -178,6 +178,19 @@ int fdtd3d_sumsq(fdtd3d_handle h, int id, double* out, void* stream);
  * bit-exact comparisons at sizes too large to download. */
 int fdtd3d_checksum(fdtd3d_handle h, int id, uint64_t* out, void* stream);
 
+/* fdtd3d_sumsq() and fdtd3d_checksum() for up to FDTD3D_REDUCE_STATIC_MAX field arrays in one call that
+ * allocates nothing.  No counterpart in the reference: it is for callers that cannot allocate device
+ * memory -- tight serving loops, harnesses that forbid hipMalloc.  The partial sums of the reduction
+ * kernel live in a file-scope device array of the library (131,456 bytes on every GPU the library is
+ * used on, held until the process ends) instead of memory from hipMalloc; the call makes no
+ * hipMalloc/hipFree and uses no allocating host container.  ids[q] in 0..17 must be resident in the
+ * engine's storage mode; sumsq[q] / checksum[q] receive what fdtd3d_sumsq / fdtd3d_checksum return for
+ * ids[q], bit for bit (either output may be NULL).  More than FDTD3D_REDUCE_STATIC_MAX arrays are
+ * refused with FDTD_ERR_ARG.  All calls on one GPU share that GPU's array: calls that overlap in time
+ * on one GPU (from several threads, handles or streams) race.  Synchronises `stream` before returning. */
+#define FDTD3D_REDUCE_STATIC_MAX 16
+int fdtd3d_reduce_static(fdtd3d_handle h, const int* ids, int n_ids, double* sumsq, uint64_t* checksum, void* stream);
+
 /* Cell-centre observables, computed on the device so that the host loop of FDTD3D::run()
  * (FDTD3D.cpp:1068-1108) never downloads the fields.  Arrays are [Nz][Ny][Nx] with x fastest, the
  * order run()/dumpFrame() hand to the VTI writer (FDTD3D.cpp:1028-1030); a slab engine fills the
