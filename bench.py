@@ -307,7 +307,8 @@ def main():
                                    "lean": "D,B resident; E=D/eps, H=B/mu recomputed in the consuming kernel; two kernels per step",
                                    "full": "D,E,B,H resident; two kernels per step"}[mode_name],
                        "launch_shape": eng.launch_shape(),
-                       "device_bytes_per_gpu": eng.device_bytes(), "placement_probe_ms": [round(v, 3) for v in eng.placement_probes()]},
+                       "device_bytes_per_gpu": eng.device_bytes(), "placement_probe_ms": [round(v, 3) for v in eng.placement_probes()],
+                       "physical_gap_between_arrays_gib": eng.spread_gap_gib()},
             "roofline": roof,
             "launches": launches,
             "checks": {"finite": bool(finite), "sumsq_dx_rank0": ex_energy, "checksum_dx": csum},

@@ -263,6 +263,8 @@ struct fdtd3d_engine {
     virtual size_t device_bytes() = 0;
     virtual int tune(int chunk, int remap, int rows) = 0;
     virtual void launch_shape(int out[6]) = 0;
+    virtual int grant_access(int peer) = 0;
+    virtual double spread_gap() = 0;
     virtual int observe_accumulate(double weight, int reset, hipStream_t s) = 0;
     virtual int observe_rms(double* host, size_t n) = 0;
     virtual int observe_frame(double* ex_center, double* e_mag, size_t n, hipStream_t s) = 0;
@@ -301,8 +303,25 @@ struct Engine3 : fdtd3d_engine {
     static constexpr int kRemapAuto = 65536;
     int chunk = 8, remap = kRemapAuto, wpb = 4;
     std::vector<void*> allocs;
+    // arena backed through the virtual-memory API (spread placement, below): the reserved range and the physical
+    // chunks mapped into it
+    char* vm_base = nullptr;
+    size_t vm_size = 0;
+    std::vector<hipMemGenericAllocationHandle_t> vm_chunks;
+    std::vector<size_t> big_starts;       // planning: arena offsets at which the large arrays begin
+    double spread_gap_gib = 0;            // physical memory left out between two large arrays (0: not spread)
+
+    void vm_release() {
+        if (vm_base) {
+            (void)hipMemUnmap(vm_base, vm_size);
+            for (auto h : vm_chunks) (void)hipMemRelease(h);
+            (void)hipMemAddressFree(vm_base, vm_size);
+        }
+        vm_base = nullptr; vm_size = 0; vm_chunks.clear();
+    }
 
     ~Engine3() override {
+        vm_release();
         for (void* p : allocs) (void)hipFree(p);
         if (stage_d) (void)hipFree(stage_d);
         probes.release();
@@ -352,7 +371,7 @@ struct Engine3 : fdtd3d_engine {
         if (nbytes == 0) { *p = nullptr; return FDTD_OK; }
         size_t span = (nbytes + kGranule - 1) / kGranule * kGranule;
         if (nbytes >= ((size_t)256 << 20)) span += gap_bytes;      // experiment: spread the big arrays
-        if (planning) { arena_used += span; *p = nullptr; return FDTD_OK; }
+        if (planning) { if (nbytes >= ((size_t)256 << 20)) big_starts.push_back(arena_used); arena_used += span; *p = nullptr; return FDTD_OK; }
         if (arena && arena_used + span <= arena_cap) {
             *p = arena + arena_used;
             arena_used += span;
@@ -391,6 +410,75 @@ struct Engine3 : fdtd3d_engine {
         *ms_per_step = ms / 4;
         return FDTD_OK;
     }
+
+    // Spread placement.  The step kernels stream from all large arrays at once, and how fast that goes depends on how
+    // far apart those arrays lie in PHYSICAL device memory: next to one another (what one big allocation gives) is the
+    // slowest arrangement, a few GiB of other memory between two arrays the fastest (measured: 17.8 ms per 1024^3 step
+    // with no gaps, 16.8 with 3 GiB, 16.65 with 7 GiB; tools/stream_spread.hip shows the same for a plain 18-read +
+    // 6-write march).  The arena is therefore a reserved virtual range backed by 128 MiB physical chunks that are
+    // created one after the other -- the driver hands physical memory out in order -- and in front of every large array
+    // `gap` bytes worth of chunks are created too and released again as soon as the whole arena is mapped: the virtual
+    // layout stays compact, the process only holds the memory of the arrays, and the arrays lie `gap` apart physically.
+    // Returns FDTD_OK with vm_base == nullptr if the device cannot do it (the caller falls back to one allocation).
+    int place_spread(size_t gap) {
+        constexpr size_t kChunk = (size_t)128 << 20;
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = device;
+        const size_t total = (arena_cap + kChunk - 1) / kChunk * kChunk;
+        char* base = nullptr;
+        if (hipMemAddressReserve((void**)&base, total, kChunk, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return FDTD_OK; }
+        vm_base = base; vm_size = total;
+        std::vector<hipMemGenericAllocationHandle_t> dropped;
+        const size_t gap_chunks = gap / kChunk;
+        size_t next_big = 1;                                   // nothing is left out in front of the first array
+        bool ok = true;
+        size_t mapped = 0;
+        for (size_t off = 0; off < total && ok; off += kChunk) {
+            // a chunk in which the next large array begins: leave `gap` of physical memory out before it
+            while (next_big < big_starts.size() && big_starts[next_big] < off + kChunk) {
+                for (size_t g = 0; g < gap_chunks && ok; ++g) {
+                    hipMemGenericAllocationHandle_t h;
+                    if (hipMemCreate(&h, kChunk, &prop, 0) == hipSuccess) dropped.push_back(h); else { (void)hipGetLastError(); g = gap_chunks; }   // out of memory: smaller gaps from here on
+                }
+                ++next_big;
+            }
+            hipMemGenericAllocationHandle_t h;
+            if (hipMemCreate(&h, kChunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+            vm_chunks.push_back(h);
+            if (hipMemMap(base + off, kChunk, 0, h, 0) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+            mapped = off + kChunk;
+        }
+        for (auto h : dropped) (void)hipMemRelease(h);
+        if (ok) {
+            hipMemAccessDesc acc = {};
+            acc.location = prop.location;
+            acc.flags = hipMemAccessFlagsProtReadWrite;
+            ok = hipMemSetAccess(base, total, &acc, 1) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+        }
+        if (!ok) {
+            if (mapped) (void)hipMemUnmap(base, mapped);
+            for (auto h : vm_chunks) (void)hipMemRelease(h);
+            (void)hipMemAddressFree(base, total);
+            vm_base = nullptr; vm_size = 0; vm_chunks.clear();
+            return FDTD_OK;
+        }
+        spread_gap_gib = (double)(gap_chunks * kChunk) / (double)((size_t)1 << 30);
+        return FDTD_OK;
+    }
+    // Lets device `peer` read and write the arena (copies between the devices of neighbouring slabs).
+    int grant_access(int peer) override {
+        if (!vm_base || peer == device) return FDTD_OK;
+        hipMemAccessDesc acc = {};
+        acc.location.type = hipMemLocationTypeDevice;
+        acc.location.id = peer;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        FDTD_HIP(hipMemSetAccess(vm_base, vm_size, &acc, 1));
+        return FDTD_OK;
+    }
+    double spread_gap() override { return spread_gap_gib; }
 
     int allocate_all() {
         int rc;
@@ -458,7 +546,7 @@ struct Engine3 : fdtd3d_engine {
 
         int rc;
         if (const char* e = getenv("FDTD_ARENA_GAP_KB")) gap_bytes = (size_t)atoll(e) << 10;
-        planning = true; arena_used = 0;
+        planning = true; arena_used = 0; big_starts.clear();
         if ((rc = allocate_all())) return rc;
         planning = false;
         arena_cap = arena_used;
@@ -472,6 +560,34 @@ struct Engine3 : fdtd3d_engine {
         if (const char* e = getenv("FDTD_PLACEMENT_TRIES")) { int v = atoi(e); if (v >= 1 && v <= 16) tries = v; }
         int explore = 3;                 // placements timed before the first may be accepted
         if (const char* e = getenv("FDTD_PLACEMENT_EXPLORE")) { int v = atoi(e); if (v >= 1 && v <= 16) explore = v; }
+        // Engines that hold a whole grid of >= 8 GiB spread their large arrays over physical memory instead (see
+        // place_spread): up to 6 GiB between two arrays, less where the device does not have that much free; no search
+        // is needed then.  FDTD_SPREAD=0 turns it off, FDTD_SPREAD=1 also spreads slab engines and small ones,
+        // FDTD_SPREAD_GAP_MB sets the gap.
+        bool want_spread = arena_cap >= ((size_t)8 << 30) && d.z_lo == 0 && d.z_hi == d.Nz;
+        if (const char* e = getenv("FDTD_SPREAD")) want_spread = e[0] == '1';
+        if (getenv("FDTD_PLACEMENT_SCAN_MB") || getenv("FDTD_NO_ARENA") || getenv("FDTD_PLACEMENT_TRIES") || gap_bytes) want_spread = want_spread && getenv("FDTD_SPREAD");
+        if (want_spread) {
+            size_t free_b = 0, total_b = 0;
+            FDTD_HIP(hipMemGetInfo(&free_b, &total_b));
+            size_t gap = (size_t)6 << 30;
+            if (const char* e = getenv("FDTD_SPREAD_GAP_MB")) gap = (size_t)std::max(0ll, atoll(e)) << 20;
+            const size_t reserve = (size_t)2 << 30, n_gaps = big_starts.size() > 1 ? big_starts.size() - 1 : 1;
+            const size_t room = free_b > arena_cap + reserve ? free_b - arena_cap - reserve : 0;
+            gap = std::min(gap, room / n_gaps);
+            if ((rc = place_spread(gap))) return rc;
+            if (vm_base) {
+                arena = vm_base; arena_used = 0; bytes = 0;
+                if ((rc = allocate_all())) return rc;
+                if (getenv("FDTD_PLACEMENT_DEBUG")) {
+                    double ms = 0;
+                    if ((rc = probe(&ms))) return rc;
+                    placement_log.push_back(ms);
+                    fprintf(stderr, "[fdtd] arena spread over physical memory, %.2f GiB between large arrays: %.3f ms/step\n", spread_gap_gib, ms);
+                }
+                tries = 0;
+            }
+        }
         // Experiment / alternative: FDTD_PLACEMENT_SCAN_MB="0,256,512" makes ONE allocation with room for the
         // largest offset, times the arena at each offset inside it (no free + allocate in between) and keeps
         // the fastest.
@@ -479,7 +595,7 @@ struct Engine3 : fdtd3d_engine {
         if (const char* e = getenv("FDTD_PLACEMENT_SCAN_MB")) {
             for (const char* q = e; *q;) { char* end = nullptr; const long v = strtol(q, &end, 10); if (end == q) break; if (v >= 0) scan.push_back((size_t)v << 20); q = *end ? end + 1 : end; }
         }
-        if (!scan.empty()) {
+        if (!scan.empty() && !vm_base) {
             const size_t slack = *std::max_element(scan.begin(), scan.end());
             char* base = nullptr;
             FDTD_HIP(hipMalloc((void**)&base, arena_cap + slack));
@@ -497,6 +613,15 @@ struct Engine3 : fdtd3d_engine {
             }
             arena = base + best_off; arena_used = 0; bytes = 0;
             if ((rc = allocate_all())) return rc;
+            tries = 0;
+        }
+        // Experiment: FDTD_NO_ARENA=1 gives every array a device allocation of its own (no common arena, no search)
+        if (const char* e = getenv("FDTD_NO_ARENA")) if (e[0] == '1' && scan.empty() && !vm_base) {
+            arena = nullptr; arena_cap = 0; arena_used = 0; bytes = 0;
+            if ((rc = allocate_all())) return rc;
+            double ms = 0;
+            if (getenv("FDTD_PLACEMENT_DEBUG") && !(rc = probe(&ms))) placement_log.push_back(ms);
+            if (rc) return rc;
             tries = 0;
         }
         double best = 1e300, worst = 0;
@@ -1193,6 +1318,8 @@ int fdtd3d_reduce_static(fdtd3d_handle h, const int* ids, int n_ids, double* sum
     return entry(h, [&] { return h->reduce_static(ids, n_ids, sumsq, checksum, (hipStream_t)stream); });
 }
 size_t fdtd3d_device_bytes(fdtd3d_handle h) { return h ? h->device_bytes() : 0; }
+int fdtd3d_grant_peer_access(fdtd3d_handle h, int peer_device) { return entry(h, [&] { return h->grant_access(peer_device); }); }
+double fdtd3d_spread_gap_gib(fdtd3d_handle h) { return h ? h->spread_gap() : 0.0; }
 int fdtd3d_launch_shape(fdtd3d_handle h, int out[6]) {
     if (!h || !out) return fail(FDTD_ERR_ARG, "null argument");
     h->launch_shape(out);

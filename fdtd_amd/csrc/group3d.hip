@@ -197,6 +197,11 @@ int build_group(fdtd3d_group* g, const fdtd3d_desc* desc, int n_slabs, const int
                 (void)hipGetLastError();                 // already enabled by someone else: fine
         }
     }
+    // an arena backed through the virtual-memory API is only visible to other devices once they have been granted access
+    for (int r = 0; r < n_slabs; ++r)
+        for (int nb : {r - 1, r + 1})
+            if (nb >= 0 && nb < n_slabs && g->device[nb] != g->device[r])
+                if (int rc = fdtd3d_grant_peer_access(g->member[r], g->device[nb])) return rc;
     const size_t R = (size_t)n_slabs;
     g->run.assign(R, nullptr); g->up.assign(R, nullptr); g->down.assign(R, nullptr);
     g->edge_done.assign(R, nullptr); g->top_done.assign(R, nullptr); g->sent_down.assign(R, nullptr); g->sent_up.assign(R, nullptr);

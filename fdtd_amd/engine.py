@@ -226,6 +226,12 @@ class Engine3D(_Common):
         _check(lib().fdtd3d_kernel_timeline(self.h, C.c_int(cap), kinds, parts, t0, dur, C.byref(n)), "kernel_timeline")
         return [(kinds[q], parts[q], t0[q], dur[q]) for q in range(min(cap, n.value))]
 
+    def spread_gap_gib(self) -> float:
+        """GiB of physical memory left out between two field arrays (0.0: the engine's memory is one plain allocation)."""
+        f = lib().fdtd3d_spread_gap_gib
+        f.restype = C.c_double
+        return float(f(self.h))
+
     def parity(self) -> int:
         """Which of the two D/B buffer sets is current (changes with every fused step)."""
         return lib().fdtd3d_buffer_parity(self.h)

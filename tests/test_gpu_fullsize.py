@@ -107,14 +107,30 @@ def test_fused_equals_lean_1024_headline_workload():
     lean.close()
     assert e_lean > 0 and np.isfinite(e_lean)
     fused = make(N, (20,) * 6, E.MODE_FUSED, True, steps=steps)
-    probes = fused.placement_probes()          # an engine this large times a few placements of its arena at creation
-    assert 3 <= len(probes) <= 8 and all(5.0 < ms < 100.0 for ms in probes)
-    assert probes[-1] <= min(probes) + 0.36 * (max(probes) - min(probes)) + 0.01 or len(probes) == 8
+    # an engine this large either spreads its field arrays over physical memory (whole grids, the default) or times a
+    # few placements of one allocation at creation (slab engines, FDTD_SPREAD=0)
+    probes = fused.placement_probes()
+    if fused.spread_gap_gib() > 0:
+        assert len(probes) <= 1
+    else:
+        assert 3 <= len(probes) <= 8 and all(5.0 < ms < 100.0 for ms in probes)
+        assert probes[-1] <= min(probes) + 0.36 * (max(probes) - min(probes)) + 0.01 or len(probes) == 8
     fused.step(0, 4)
     fused.tune(5, 0, 8)
     fused.step(4, steps - 4)
     assert [fused.checksum(i) for i in FIELDS] == want
     fused.close()
+
+
+def test_placement_search_when_spreading_is_off(monkeypatch):
+    """FDTD_SPREAD=0: one plain allocation, placed up to eight times and timed (the path slab engines take)."""
+    monkeypatch.setenv("FDTD_SPREAD", "0")
+    eng = make((1024, 1024, 256), (20,) * 6, E.MODE_FUSED, True, steps=4)      # 21 GB: large enough to be searched
+    probes = eng.placement_probes()
+    assert eng.spread_gap_gib() == 0 and 3 <= len(probes) <= 8 and all(1.0 < ms < 50.0 for ms in probes)
+    eng.step(0, 3)
+    assert np.isfinite(eng.sumsq(E.DX))
+    eng.close()
 
 
 def test_fused_slabs_equal_whole_grid_384():
