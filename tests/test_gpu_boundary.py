@@ -132,3 +132,54 @@ def test_empty_waveform_and_steps_past_its_end(mode):
     for id_ in (E.DX, E.DY, E.DZ, E.BX, E.BY, E.BZ):
         a, b = eng.get(id_), tw.get(id_)
         assert np.array_equal(a, b) and (id_ != E.DX or np.abs(a).max() > 0)
+
+
+def test_timeline_launch_shape_fill_and_placement_calls(monkeypatch):
+    """The measurement hooks added beside the step functions: per-launch timeline, launch shape, array fill, and the
+    placement queries -- what they report, and what they refuse."""
+    L = E.lib()
+    null = C.c_void_p(0)
+    n = C.c_int(-1)
+    assert L.fdtd3d_kernel_timeline(null, 0, None, None, None, None, C.byref(n)) == 1
+    assert L.fdtd3d_launch_shape(null, (C.c_int * 6)()) == 1 and L.fdtd3d_fill_array(null, 0, 1, C.c_double(0), C.c_double(1)) == 1
+    assert L.fdtd3d_grant_peer_access(null, 0) == 1
+    L.fdtd3d_spread_gap_gib.restype = C.c_double
+    assert L.fdtd3d_spread_gap_gib(null) == 0.0
+    eng = make3(mode=E.MODE_FUSED, z_range=(4, 20))
+    assert eng.kernel_timeline() == []                               # nothing timed yet
+    eng.kernel_timing(True)
+    for step in range(3):
+        eng.fused(step, E.PART_EDGE)
+        eng.fused(step, E.PART_TOP)
+        eng.fused_top()
+        eng.fused(step, E.PART_INTERIOR)
+    tl = eng.kernel_timeline()
+    assert [(k, p) for k, p, _, _ in tl] == [(2, E.PART_EDGE), (2, E.PART_TOP), (1, E.PART_EDGE), (2, E.PART_INTERIOR)] * 3
+    starts = [t for _, _, t, _ in tl]
+    assert starts == sorted(starts) and starts[0] == 0.0 and all(d > 0 for _, _, _, d in tl)
+    assert len(eng.kernel_timeline()) == 12                          # reading the timeline leaves the records in place
+    assert eng.kernel_time(2)[0] == 9 and eng.kernel_time(1)[0] == 3 and eng.kernel_timeline() == []
+    shape = eng.launch_shape()
+    assert shape["rows_per_group"] in (8, 16) and shape["edge_planes"] == 1 and shape["row_pitch"] % 256 == 0 and shape["planes_per_group"] >= 1
+    eng.tune(3, 0, 5)
+    assert (eng.launch_shape()["planes_per_group"], eng.launch_shape()["xcd_run"], eng.launch_shape()["rows_per_group"]) == (3, 0, 5)
+    # fill_array: resident field arrays only
+    eng.fill_array(E.DX, 3, -1.0, 1.0)
+    assert eng.sumsq(E.DX) > 0
+    with pytest.raises(E.EngineError, match="not a resident field"):
+        eng.fill_array(E.EX, 3, 0.0, 1.0)                            # E is not stored in FUSED mode
+    with pytest.raises(E.EngineError, match="not a resident field"):
+        eng.fill_array(99, 3, 0.0, 1.0)
+    # a small engine is one plain allocation; granting access to its own device is a no-op either way
+    assert eng.spread_gap_gib() == 0.0 and L.fdtd3d_grant_peer_access(eng.h, 0) == 0
+    # the same engine backed through the virtual-memory API steps to the same bits
+    want = [eng.checksum(i) for i in (E.DX, E.DY, E.BZ)]
+    monkeypatch.setenv("FDTD_SPREAD", "1")
+    vm = make3(mode=E.MODE_FUSED, z_range=(4, 20))
+    vm.tune(3, 0, 5)
+    vm.fill_array(E.DX, 3, -1.0, 1.0)
+    for e in (eng, vm):
+        e.fused(3, E.PART_ALL)
+        e.fused_top()
+    want = [eng.checksum(i) for i in (E.DX, E.DY, E.BZ)]
+    assert [vm.checksum(i) for i in (E.DX, E.DY, E.BZ)] == want and L.fdtd3d_grant_peer_access(vm.h, 0) == 0
