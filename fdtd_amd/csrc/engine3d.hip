@@ -1117,7 +1117,7 @@ struct Engine3 : fdtd3d_engine {
     void launch_fused(K3<T> a, hipStream_t s) {
         a.nbx = px / (kLanes * FV);
         const unsigned nblk = (unsigned)a.nbx * a.nby * a.nbz;
-        const size_t lds = (size_t)2 * wpbf * 3 * kLanes * FV * sizeof(T);
+        const size_t lds = ((size_t)2 * wpbf * 3 + 7) * kLanes * FV * sizeof(T);       // E rows of two planes + the tile's x coefficients
         auto go = [&](auto kern) {
             // more than 64 KB of dynamic LDS has to be allowed per kernel
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
