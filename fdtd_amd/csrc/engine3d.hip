@@ -284,7 +284,7 @@ struct Engine3 : fdtd3d_engine {
     bool last_rank = false, full = true, fused = false;
     T* alt[18] = {nullptr};           // fused stepping: the other D and B buffers of the ping-pong
     T* phE2[3][3][2];
-    int wpbf = 16;                    // fused kernel: waves per workgroup (the last one is a halo row)
+    int wpbf = 8;                     // fused kernel: waves per workgroup (the last one is a halo row)
     int edge_planes = 1;              // fused kernel on a slab: planes of the EDGE and of the TOP launch (FDTD_EDGE_PLANES)
     int fvec = VecWidth<T>::V;        // fused kernel: elements per lane (V or V/2)
     size_t plane = 0, fsize = 0, bytes = 0;
@@ -532,12 +532,13 @@ struct Engine3 : fdtd3d_engine {
         if (fused) {
             // The closing plane of a chunk is computed twice, so long chunks pay off -- once there are enough
             // workgroups to fill 256 CUs several times over.  Small grids (the reference's own 200^3) get shorter
-            // chunks, down to 4 planes, and launches that stay below 1600 workgroups 8 instead of 16 rows per
-            // group (200^3: 0.21 ms per step instead of 0.39).
+            // chunks, down to 4 planes.  Workgroups have 8 waves (7 rows + the halo row): two of them share a CU and
+            // run out of step with each other, which keeps memory busy while one of them sits at its per-plane barrier
+            // -- since the kernel waits for memory only once per plane that is worth more than the halo rows the
+            // 16-wave shape saves (1024^3: 15.3 against 15.8 ms; 512^3: 1.56 against 1.65; fdtd3d_tune selects 16).
             const int per_chunk = (px / (kLanes * fvec)) * ((ny1 + 14) / 15);
             const int chunks_wanted = (1400 + per_chunk - 1) / per_chunk;
             chunk = std::max(4, std::min(24, nzl / std::max(1, chunks_wanted)));
-            if (per_chunk * ((nzl + chunk - 1) / chunk) < 1600) wpbf = 8;
         }
         if (const char* e = getenv("FDTD_EDGE_PLANES")) { int c = atoi(e); if (c >= 1 && c <= 64) edge_planes = c; }
         if (const char* e = getenv("FDTD_Z_CHUNK")) { int c = atoi(e); if (c >= 1 && c <= 4096) chunk = c; }
@@ -554,11 +555,11 @@ struct Engine3 : fdtd3d_engine {
         // the step kernels by up to 10 % (measured: the same binary and virtual address run a 1024^3 step
         // in 18.1, 18.9 or 20.0 ms, cycling with every free + allocate, across processes).  For large
         // grids the arena is therefore placed a few times, each placement timed with four source-free
-        // steps on the zero state (which they leave unchanged); after three placements the first one in
+        // steps on the zero state (which they leave unchanged); after five placements the first one in
         // the fast fifth of the range seen so far is kept (an earlier placement cannot be returned to).
         int tries = arena_cap >= ((size_t)8 << 30) ? 8 : 1;
         if (const char* e = getenv("FDTD_PLACEMENT_TRIES")) { int v = atoi(e); if (v >= 1 && v <= 16) tries = v; }
-        int explore = 3;                 // placements timed before the first may be accepted
+        int explore = 5;                 // placements timed before the first may be accepted
         if (const char* e = getenv("FDTD_PLACEMENT_EXPLORE")) { int v = atoi(e); if (v >= 1 && v <= 16) explore = v; }
         // Engines that hold a whole grid of >= 8 GiB spread their large arrays over physical memory instead (see
         // place_spread): up to 6 GiB between two arrays, less where the device does not have that much free; no search

@@ -231,7 +231,7 @@ int fdtd3d_grant_peer_access(fdtd3d_handle h, int peer_device);
 /* Engines that are not spread (slab engines; FDTD_SPREAD=0) are placed in device memory up to FDTD_PLACEMENT_TRIES
  * times (environment, default 8, 1 = off) at creation: where the driver puts a large allocation
  * changes the streaming rate of the step kernels by several percent, so each placement is timed with
- * a few source-free steps on the zero state and, after three, the first one in the fast fifth of the
+ * a few source-free steps on the zero state and, after five, the first one in the fast fifth of the
  * range seen is kept.
  * Returns how many placements were timed and copies up to `cap` of their step times (ms). */
 int fdtd3d_placement_probes(fdtd3d_handle h, double* ms_per_step, int cap);

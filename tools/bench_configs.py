@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Step times of the other BASELINE configurations and storage modes on one MI355X (markdown table rows):
     python tools/bench_configs.py"""
-import sys, time
+import os, sys, time
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch, numpy as np
 import fdtd_amd
@@ -18,6 +18,8 @@ def run(tag, N, npml, prec, has_mu, mode, dipole=False, steps=20):
     if has_mu: eng.fill_materials(1234, K["eps0"], 4*K["eps0"], K["mu0"], 2*K["mu0"])
     elif dipole: eng.fill_materials(1234, K["eps0"], K["eps0"], K["mu0"], K["mu0"])
     else: eng.fill_materials(1234, K["eps0"], 4*K["eps0"], K["mu0"], K["mu0"])
+    if os.environ.get("FDTD_TUNE_ROWS"):          # experiment: rows per workgroup of the fused kernel
+        eng.tune(int(os.environ.get("FDTD_TUNE_CHUNK", "0")), -1, int(os.environ["FDTD_TUNE_ROWS"]))
     eng.step(0, 5); torch.cuda.synchronize()
     t0 = time.perf_counter(); eng.step(5, steps); torch.cuda.synchronize(); el = (time.perf_counter()-t0)/steps
     cells = N[0]*N[1]*N[2]

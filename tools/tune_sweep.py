@@ -37,8 +37,8 @@ def timed(count=6):
 
 base = timed()
 print(f"default {eng.launch_shape()}: {base:.3f} ms", flush=True)
-for rows in (16, 12, 8):
-    for chunk in (12, 16, 24, 32, 48, 64):
-        for remap in (0, 2, 4, 8, 16):
+for rows in (16, 8):
+    for chunk in (16, 24, 32, 48):
+        for remap in (2, 4, 8):
             eng.tune(chunk, remap, rows)
             print(f"rows {rows:2d} chunk {chunk:2d} remap {remap:2d}: {timed():.3f} ms", flush=True)
