@@ -105,6 +105,10 @@ __global__ void __launch_bounds__(kLanes * kStack2D) k2_fused(const K2F<T> a) {
     const bool from_above = ke < a.nz1 && w + 1 < kStack2D;   // the closing row's Ey_new comes from the wave above
     const bool src_lane = valid && a.iJ >= i0 && a.iJ < i0 + V;
 
+    // "any dispersive cell in this row segment / in the one to its left": fetched one row ahead, so that no row starts
+    // by waiting for its flag
+    unsigned char pf = a.disp[(size_t)kb * a.ntx + tx], pfl = c0 > 0 ? a.disp[(size_t)kb * a.ntx + tx - 1] : (unsigned char)0;
+
     size_t ro = (size_t)kb * px + c0;                    // uniform offset of the wave's row segment
     P hx_km = zero_pack<T, V>();
     if (kb >= 1) {
@@ -119,7 +123,11 @@ __global__ void __launch_bounds__(kLanes * kStack2D) k2_fused(const K2F<T> a) {
     for (int k = kb; k < k_end; ++k, ro += px) {
         asm volatile("" : "+s"(ap));
         const bool own_row = k < ke;
-        const bool flag = __builtin_amdgcn_readfirstlane((int)a.disp[(size_t)k * a.ntx + tx]) != 0;
+        const bool flag = __builtin_amdgcn_readfirstlane((int)pf) != 0, flag_left = __builtin_amdgcn_readfirstlane((int)pfl) != 0;
+        if (k + 1 < k_end) {
+            pf = a.disp[(size_t)(k + 1) * a.ntx + tx];
+            if (c0 > 0) pfl = a.disp[(size_t)(k + 1) * a.ntx + tx - 1];
+        }
         int lk;
         const int zk = zone_e(k, Nz, a.np[1][0], a.np[1][1], lk);
         const bool row_in = k >= 1 && k < Nz, row_lt = k < Nz;
@@ -130,6 +138,8 @@ __global__ void __launch_bounds__(kLanes * kStack2D) k2_fused(const K2F<T> a) {
             ey = ldv<T, V>(&handover[w + 1][lane * V]);
         } else {
         P d = ldg<T, V>(ap->Dy + ro, lo); bxo = ldg<T, V>(ap->Bx + ro, lo), bzo = ldg<T, V>(ap->Bz + ro, lo);
+        T bz_left = (T)0;                                 // lane 0: Bz to the left of the tile, requested with the row
+        if (lane == 0 && c0 > 0) bz_left = ldg1<T>(ap->Bz + ro - 1);
         if (!valid) { d = zero_pack<T, V>(); bxo = d; bzo = d; }
         hx = field_of<T, V>(bxo, a.mu0, flag, ap->H1[0] + ro, ap->C1 + ro, ap->C2 + ro, ap->C3 + ro, lo);
         P hz = field_of<T, V>(bzo, a.mu0, flag, ap->H1[1] + ro, ap->C1 + ro, ap->C2 + ro, ap->C3 + ro, lo);
@@ -138,9 +148,8 @@ __global__ void __launch_bounds__(kLanes * kStack2D) k2_fused(const K2F<T> a) {
         if (lane == 0) {
             hz_l = (T)0;
             if (c0 > 0) {
-                const bool fl = a.disp[(size_t)k * a.ntx + tx - 1] != 0;
                 const size_t q = ro - 1;
-                hz_l = field_of1<T>(ldg1<T>(ap->Bz + q), a.mu0, fl, ap->H1[1] + q, ap->C1 + q, ap->C2 + q, ap->C3 + q);
+                hz_l = field_of1<T>(bz_left, a.mu0, flag_left, ap->H1[1] + q, ap->C1 + q, ap->C2 + q, ap->C3 + q);
             }
         }
         const bool st = own_row && owned;
