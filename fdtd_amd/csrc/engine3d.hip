@@ -1,5 +1,6 @@
 // engine3d.hip -- host side of the 3-D engine: device state, array exchange, launches, C ABI.
 #include "kernels3d_fused.hpp"
+#include "kernels3d_pair.hpp"
 #include "../../include/fdtd_setup.h"
 
 #include <algorithm>
@@ -249,6 +250,8 @@ struct fdtd3d_engine {
     virtual int half_h(int part, hipStream_t s) = 0;
     virtual int step(int n, hipStream_t s) = 0;
     virtual int fused_part(int n, int part, hipStream_t s) = 0;
+    virtual int step_pair(int n, hipStream_t s) = 0;
+    virtual int pair_shape(int chunk, int rows) = 0;
     virtual int parity() = 0;
     virtual int fused_top(hipStream_t s) = 0;
     virtual int placement(double* ms, int cap) = 0;
@@ -1197,6 +1200,49 @@ struct Engine3 : fdtd3d_engine {
         return FDTD_OK;
     }
 
+    // ---- two steps per launch (kernels3d_pair.hpp) ----------------------------------------------
+    int wpbp = 16, chunk_pair = 48;
+    int pair_shape(int chunk_, int rows) override {
+        if (chunk_ > 0) chunk_pair = chunk_;
+        if (rows >= 6 && rows <= 16) wpbp = rows;
+        return FDTD_OK;
+    }
+    int step_pair(int n, hipStream_t s) override {
+        if (!fused) return fail(FDTD_ERR_STATE, "two-step launches need an engine created with FDTD3D_MODE_FUSED");
+        if (d.z_lo != 0 || d.z_hi != d.Nz) return fail(FDTD_ERR_STATE, "two-step launches need the whole grid on this device");
+        for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd)
+            if (np[ax][sd] != 0) return fail(FDTD_ERR_STATE, "two-step launches do not carry CPML layers (axis %d has %d)", ax, np[ax][sd]);
+        if (phase != 0) return fail(FDTD_ERR_STATE, "two-step launch in the middle of a split step");
+        constexpr int PV = V / 2, TW = kLanes * PV, XS = TW - 4;
+        K3<T> a = args();
+        const bool s1 = n >= 0 && n < (int)wf.size(), s2 = n + 1 >= 0 && n + 1 < (int)wf.size();
+        a.src_on = (s1 ? 1 : 0) | (s2 ? 2 : 0);
+        a.jx = s1 ? a.dt * wf[n] : (T)0;
+        a.jx2 = s2 ? a.dt * wf[n + 1] : (T)0;
+        for (int c = 0; c < 3; ++c) { a.Dn[c] = alt[c]; a.Bn[c] = alt[6 + c]; }
+        const int cover = std::min(d.Nx + 1, px);            // columns that hold anything
+        a.nbx = cover > TW - 2 ? (cover - (TW - 2) + XS - 1) / XS + 1 : 1;
+        a.wpb = wpbp;
+        a.nby = (ny1 + (wpbp - 3) - 1) / (wpbp - 3);
+        a.chunk = chunk_pair;
+        a.kl0 = 1; a.kl1 = nzp;
+        a.nbz = (a.kl1 - a.kl0 + a.chunk - 1) / a.chunk;
+        a.remap = remap == kRemapAuto ? std::max(2, a.nbx) : remap;
+        const unsigned nblk = (unsigned)a.nbx * a.nby * a.nbz;
+        const size_t lds = ((size_t)2 + (size_t)3 * 2 * wpbp * 2) * TW * sizeof(T);
+        auto go = [&](auto kern) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(nblk), dim3(kLanes * wpbp), lds, s, a);
+        };
+        timer.begin(3, s, 0);
+        if (d.has_mu) go(k3_pair<T, true, PV>); else go(k3_pair<T, false, PV>);
+        timer.end(s);
+        FDTD_HIP(hipGetLastError());
+        for (int c = 0; c < 3; ++c) { std::swap(fld[c], alt[c]); std::swap(fld[6 + c], alt[6 + c]); }
+        ++flips;
+        return FDTD_OK;
+    }
+
     int halo(int which, int comp, void** p, size_t* nbytes, int at_parity) override {
         if (comp < 0 || comp > 1) return fail(FDTD_ERR_ARG, "halo: comp must be 0 or 1");
         if (at_parity >= 0 && !fused && at_parity != 0) return fail(FDTD_ERR_ARG, "halo: only FUSED engines have a second buffer set");
@@ -1295,6 +1341,15 @@ int fdtd3d_step(fdtd3d_handle h, int n0, int count, void* stream) {
         return FDTD_OK;
     });
 }
+int fdtd3d_step_pairs(fdtd3d_handle h, int n0, int pairs, void* stream) {
+    return entry(h, [&]() -> int {
+        if (h->probe_count() > 0) return fail(FDTD_ERR_STATE, "two-step launches cannot sample probes after the first of their steps");
+        for (int q = 0; q < pairs; ++q)
+            if (int rc = h->step_pair(n0 + 2 * q, (hipStream_t)stream)) return rc;
+        return FDTD_OK;
+    });
+}
+int fdtd3d_pair_shape(fdtd3d_handle h, int chunk, int rows) { return entry(h, [&] { return h->pair_shape(chunk, rows); }); }
 int fdtd3d_fused(fdtd3d_handle h, int n, int part, void* stream) { return entry(h, [&] { return h->fused_part(n, part, (hipStream_t)stream); }); }
 int fdtd3d_fused_top(fdtd3d_handle h, void* stream) { return entry(h, [&] { return h->fused_top((hipStream_t)stream); }); }
 int fdtd3d_probe_add(fdtd3d_handle h, int id, int i, int j, int k) { return entry(h, [&] { return h->probe_add(id, i, j, k); }); }

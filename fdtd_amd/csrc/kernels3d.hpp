@@ -54,6 +54,8 @@ struct K3 {
     T* phEn[3][3][2];
     int kl_stop;       // planes below this index may be visited for the closing D iteration of a chunk
     int copy_top;      // plane kl_stop-1 is a top layer whose B is finished later: carry it over unchanged
+    // two-step kernel only: dt * wf[n+1]; src_on bit 0 = the first step has a source term, bit 1 = the second
+    T jx2;
 };
 
 template <typename T, int V>

@@ -194,6 +194,13 @@ class Engine3D(_Common):
     def step(self, n0: int, count: int = 1, stream=None) -> None:
         _check(lib().fdtd3d_step(self.h, C.c_int(n0), C.c_int(count), _stream_handle(stream)), "fdtd3d_step")
 
+    def step_pairs(self, n0: int, pairs: int = 1, stream=None) -> None:
+        """Steps n0 .. n0+2*pairs-1, two per launch (fdtd3d_step_pairs: no CPML, whole grid, FUSED mode, no probes)."""
+        _check(lib().fdtd3d_step_pairs(self.h, C.c_int(n0), C.c_int(pairs), _stream_handle(stream)), "fdtd3d_step_pairs")
+
+    def pair_shape(self, chunk: int = 0, rows: int = 0) -> None:
+        _check(lib().fdtd3d_pair_shape(self.h, C.c_int(chunk), C.c_int(rows)), "fdtd3d_pair_shape")
+
     def half_e(self, n: int, part: int = PART_ALL, stream=None) -> None:
         _check(lib().fdtd3d_half_e(self.h, C.c_int(n), C.c_int(part), _stream_handle(stream)), "fdtd3d_half_e")
 

@@ -1,0 +1,112 @@
+"""Two steps per launch (fdtd3d_step_pairs) against the reference vectors, the twin and the one-step kernel (needs a GPU)."""
+import numpy as np
+import pytest
+
+import fdtd_amd
+from fdtd_amd.engine import MODE_FUSED
+from oracle import pyoracle as po
+from tests import util
+from tests.test_gpu_parity import engine3d_from_meta
+
+pytestmark = pytest.mark.gpu
+
+
+class Paired:
+    """Back end that advances an engine two steps per launch wherever it can."""
+
+    def __init__(self, eng):
+        self.eng = eng
+
+    def set(self, id_, a):
+        self.eng.set(id_, a)
+
+    def get(self, id_):
+        return self.eng.get(id_)
+
+    def step(self, n0, count):
+        self.eng.step_pairs(n0, count // 2)
+        if count % 2:
+            self.eng.step(n0 + count - 1, 1)
+
+
+@pytest.mark.parametrize("prec", [32, 64])
+@pytest.mark.parametrize("rows,chunk", [(16, 48), (6, 2), (9, 5)])
+def test_pairs_equal_reference_cavity(prec, rows, chunk):
+    """BASELINE's vacuum cavity (no CPML): fp64 against the reference's own vectors, fp32 against the fp32 twin, bit for bit."""
+    meta, ins, outs, _ = util.load_fixture("g2_3d_cavity")
+    assert not any(meta["npml"])
+    eng = engine3d_from_meta(meta, prec, mode=MODE_FUSED)
+    eng.pair_shape(chunk, rows)
+    util.feed(eng, ins)
+    got = util.run_snapshots(Paired(eng), meta, outs)
+    if prec == 64:
+        ref = outs
+    else:
+        tw = util.twin3d_from_meta(meta, 32)
+        util.feed(tw, ins)
+        ref = util.run_snapshots(tw, meta, outs)
+    for key in outs:
+        util.assert_equal_arrays(got[key], ref[key], f"cavity pairs fp{prec} step {key[0]} array {key[1]}")
+
+
+@pytest.mark.parametrize("prec,N", [
+    (32, (300, 9, 11)),       # three x tiles of 124 owned columns
+    (32, (126, 40, 9)),       # Nx = the first tile's owned columns exactly; more rows than one workgroup
+    (32, (256, 5, 7)),        # Nx = row pitch: the wall column is not stored
+    (32, (7, 6, 5)),
+    (64, (140, 6, 19)),       # fp64 tiles own 60 columns
+    (64, (12, 33, 9)),
+    (64, (64, 17, 4)),
+])
+@pytest.mark.parametrize("has_mu", [False, True])
+@pytest.mark.parametrize("rows,chunk", [(16, 48), (6, 2), (11, 3)])
+def test_pairs_equal_single_steps_ragged(prec, N, has_mu, rows, chunk):
+    K = po.consts()
+    d = (5e-8, 6e-8, 7e-8)
+    dt = 5e-8 / (2 * K["c0"])
+    steps = 24
+    kJ = N[2] // 2
+    npml = (0,) * 6
+    rng = np.random.default_rng(11)
+    wf, mag = po.default_source3d(N[0], N[1], steps, d, dt)
+    mag = rng.random(mag.shape)
+    eps = [K["eps0"] * (1 + 3 * rng.random(po.shape3d(po.EPS_X + c, N, npml))) for c in range(3)]
+    mu = [K["mu0"] * (1 + rng.random(po.shape3d(po.MU_X + c, N, npml))) for c in range(3)]
+    tw = po.Twin3D(prec, N, npml, d, dt, K["mu0"], kJ, steps, has_mu)
+    pair = fdtd_amd.Engine3D(N, npml, d, dt, K["mu0"], kJ, steps, precision=prec, mode=MODE_FUSED, has_mu=has_mu)
+    pair.pair_shape(chunk, rows)
+    for be in (tw, pair):
+        be.set(po.JX_WF, wf)
+        be.set(po.JX_MAG, mag)
+        for c in range(3):
+            be.set(po.EPS_X + c, eps[c])
+            if has_mu:
+                be.set(po.MU_X + c, mu[c])
+    # 3 pairs, one single step (the buffers change roles an odd number of times), then pairs that run past the
+    # end of the source waveform
+    tw.step(0, 6); pair.step_pairs(0, 3)
+    tw.step(6, 1); pair.step(6, 1)
+    for id_ in po.FIELDS3D:
+        if pair.size(id_):
+            util.assert_equal_arrays(pair.get(id_), tw.get(id_), f"N={N} step 7 array {id_}")
+    tw.step(7, 20); pair.step_pairs(7, 10)
+    for id_ in po.FIELDS3D:
+        if pair.size(id_):
+            util.assert_equal_arrays(pair.get(id_), tw.get(id_), f"N={N} step 27 array {id_}")
+
+
+def test_pairs_refuse_what_they_do_not_carry():
+    K = po.consts()
+    with_pml = fdtd_amd.Engine3D((16, 16, 16), (2, 2, 0, 0, 0, 0), (1e-7,) * 3, 1e-16, K["mu0"], 4, 3, precision=32, mode=MODE_FUSED)
+    with pytest.raises(fdtd_amd.EngineError, match="CPML"):
+        with_pml.step_pairs(0, 1)
+    slab = fdtd_amd.Engine3D((16, 16, 16), (0,) * 6, (1e-7,) * 3, 1e-16, K["mu0"], 4, 3, precision=32, mode=MODE_FUSED, z_range=(0, 8))
+    with pytest.raises(fdtd_amd.EngineError, match="whole grid"):
+        slab.step_pairs(0, 1)
+    lean = fdtd_amd.Engine3D((16, 16, 16), (0,) * 6, (1e-7,) * 3, 1e-16, K["mu0"], 4, 3, precision=32, mode=fdtd_amd.engine.MODE_LEAN)
+    with pytest.raises(fdtd_amd.EngineError, match="FUSED"):
+        lean.step_pairs(0, 1)
+    probed = fdtd_amd.Engine3D((16, 16, 16), (0,) * 6, (1e-7,) * 3, 1e-16, K["mu0"], 4, 3, precision=32, mode=MODE_FUSED)
+    probed.probe_add(po.DX, 3, 3, 3)
+    with pytest.raises(fdtd_amd.EngineError, match="probes"):
+        probed.step_pairs(0, 1)
