@@ -294,6 +294,10 @@ struct Engine3 : fdtd3d_engine {
     T* fld[18] = {nullptr};           // D E B H eps mu, three each (mu only if has_mu; E,H absent in LEAN)
     T* phE[3][3][2];
     T* phM[3][3][2];
+    T* phM2[3][3][2] = {};            // second set of the B-side CPML state: only two-step launches need it
+    bool phM2_ready = false;
+    T* pair_scr = nullptr;
+    size_t pair_scr_elems = 0;
     size_t phSize[2][3][3][2];
     T* tab_d = nullptr;
     T* xrow_d = nullptr;
@@ -707,7 +711,7 @@ struct Engine3 : fdtd3d_engine {
             for (int q = 0; q < 3; ++q) m.n[q] = isM ? N[q] + (q == m.c) : N[q] + (q != m.c);
             m.n[m.a] = np[m.a][m.s];
             m.dev = isM ? phM[m.c][m.a][m.s] : phE[m.c][m.a][m.s];
-            m.dev2 = (!isM && fused) ? phE2[m.c][m.a][m.s] : nullptr;
+            m.dev2 = isM ? (phM2_ready ? phM2[m.c][m.a][m.s] : nullptr) : (fused ? phE2[m.c][m.a][m.s] : nullptr);
             m.dev_elems = phSize[isM][m.c][m.a][m.s];
             m.kind = m.a == 2 ? 1 : (m.a == 1 ? 2 : 3);
             return true;
@@ -1210,8 +1214,8 @@ struct Engine3 : fdtd3d_engine {
     int step_pair(int n, hipStream_t s) override {
         if (!fused) return fail(FDTD_ERR_STATE, "two-step launches need an engine created with FDTD3D_MODE_FUSED");
         if (d.z_lo != 0 || d.z_hi != d.Nz) return fail(FDTD_ERR_STATE, "two-step launches need the whole grid on this device");
-        for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd)
-            if (np[ax][sd] != 0) return fail(FDTD_ERR_STATE, "two-step launches do not carry CPML layers (axis %d has %d)", ax, np[ax][sd]);
+        bool pml = false;
+        for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) pml = pml || np[ax][sd] != 0;
         if (phase != 0) return fail(FDTD_ERR_STATE, "two-step launch in the middle of a split step");
         constexpr int PV = V / 2, TW = kLanes * PV, XS = TW - 4;
         K3<T> a = args();
@@ -1219,7 +1223,16 @@ struct Engine3 : fdtd3d_engine {
         a.src_on = (s1 ? 1 : 0) | (s2 ? 2 : 0);
         a.jx = s1 ? a.dt * wf[n] : (T)0;
         a.jx2 = s2 ? a.dt * wf[n + 1] : (T)0;
-        for (int c = 0; c < 3; ++c) { a.Dn[c] = alt[c]; a.Bn[c] = alt[6 + c]; }
+        if (pml && !phM2_ready) {
+            for (int c = 0; c < 3; ++c) for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd)
+                if (phM[c][ax][sd])
+                    if (int rc = dalloc((void**)&phM2[c][ax][sd], (phSize[1][c][ax][sd] + px) * sizeof(T))) return rc;
+            phM2_ready = true;
+        }
+        for (int c = 0; c < 3; ++c) {
+            a.Dn[c] = alt[c]; a.Bn[c] = alt[6 + c];
+            for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) { a.phEn[c][ax][sd] = phE2[c][ax][sd]; a.phMn[c][ax][sd] = phM2[c][ax][sd]; }
+        }
         const int cover = std::min(d.Nx + 1, px);            // columns that hold anything
         a.nbx = cover > TW - 2 ? (cover - (TW - 2) + XS - 1) / XS + 1 : 1;
         a.wpb = wpbp;
@@ -1229,16 +1242,26 @@ struct Engine3 : fdtd3d_engine {
         a.nbz = (a.kl1 - a.kl0 + a.chunk - 1) / a.chunk;
         a.remap = remap == kRemapAuto ? std::max(2, a.nbx) : remap;
         const unsigned nblk = (unsigned)a.nbx * a.nby * a.nbz;
-        const size_t lds = ((size_t)2 + (size_t)3 * 2 * wpbp * 2) * TW * sizeof(T);
+        const size_t lds = ((size_t)6 + (size_t)3 * 2 * wpbp * 2) * TW * sizeof(T);
+        const size_t scr_need = pml ? (size_t)nblk * wpbp * 24 * TW : 0;
+        if (scr_need > pair_scr_elems) {
+            if (int rc = dalloc((void**)&pair_scr, scr_need * sizeof(T), 0)) return rc;    // the old piece stays with the engine
+            pair_scr_elems = scr_need;
+        }
+        a.pair_scr = pair_scr;
         auto go = [&](auto kern) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(kern, dim3(nblk), dim3(kLanes * wpbp), lds, s, a);
         };
         timer.begin(3, s, 0);
-        if (d.has_mu) go(k3_pair<T, true, PV>); else go(k3_pair<T, false, PV>);
+        if (pml) { if (d.has_mu) go(k3_pair<T, true, true, PV>); else go(k3_pair<T, false, true, PV>); }
+        else { if (d.has_mu) go(k3_pair<T, true, false, PV>); else go(k3_pair<T, false, false, PV>); }
         timer.end(s);
         FDTD_HIP(hipGetLastError());
-        for (int c = 0; c < 3; ++c) { std::swap(fld[c], alt[c]); std::swap(fld[6 + c], alt[6 + c]); }
+        for (int c = 0; c < 3; ++c) {
+            std::swap(fld[c], alt[c]); std::swap(fld[6 + c], alt[6 + c]);
+            if (pml) for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) { std::swap(phE[c][ax][sd], phE2[c][ax][sd]); std::swap(phM[c][ax][sd], phM2[c][ax][sd]); }
+        }
         ++flips;
         return FDTD_OK;
     }

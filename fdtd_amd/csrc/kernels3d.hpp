@@ -56,6 +56,8 @@ struct K3 {
     int copy_top;      // plane kl_stop-1 is a top layer whose B is finished later: carry it over unchanged
     // two-step kernel only: dt * wf[n+1]; src_on bit 0 = the first step has a source term, bit 1 = the second
     T jx2;
+    T* phMn[3][3][2];  // the B-side CPML state it writes (ping-pong, like phEn)
+    T* pair_scr;       // CPML state between the two steps of a launch: [workgroup][wave][2 planes][12 terms][columns of a wave]
 };
 
 template <typename T, int V>

@@ -1,4 +1,4 @@
-// kernels3d_pair.hpp -- two time steps of the 3-D update in one pass over memory (no CPML).
+// kernels3d_pair.hpp -- two time steps of the 3-D update in one pass over memory.
 //
 // The one-step fused kernel moves D, B, eps and mu across HBM once per step.  Here a workgroup marches
 // through its planes carrying TWO steps at once, so that they cross HBM once per two steps:
@@ -18,8 +18,14 @@
 // Old and new values of a cell are needed by different tiles at different times, so D and B ping-pong
 // between two buffers exactly as in the one-step fused kernel.
 //
-// Restrictions (checked by the host): no CPML layers on any face, the whole grid on one device.
+// CPML: a cell's auxiliary state is advanced twice as well.  Between its two steps it waits in a per-wave
+// piece of device memory (`pair_scr`): written in stage A/B, read back one iteration later in stage C/D, so it
+// normally never leaves L2; both the D-side and the B-side state ping-pong between two buffers, because halo
+// cells recompute their first step from the OLD state after the owner may have stored the new one.
+//
+// Restriction (checked by the host): the whole grid on one device.
 #pragma once
+#include <type_traits>
 #include "kernels3d_fused.hpp"
 
 namespace fdtd {
@@ -59,53 +65,37 @@ __device__ __forceinline__ void pair_axpy_x(Pack<T, V>& d, const Pack<T, V>& c, 
     for (int e = 0; e < V; ++e) { const T v = c.v[e] * curl.v[e]; d.v[e] = SIGN > 0 ? d.v[e] + v : d.v[e] - v; }
 }
 
-// D of one plane from H of the same step: the terms, their order and their index ranges are those of k3_fused
-// with every zone "plain" (1 <= k < Nz for the z term and so on).
-template <typename T, int V>
-__device__ __forceinline__ void pair_update_d(Pack<T, V>& dx, Pack<T, V>& dy, Pack<T, V>& dz,
-                                              const Pack<T, V>& hx, const Pack<T, V>& hy, const Pack<T, V>& hz,
-                                              const Pack<T, V>& hx_km, const Pack<T, V>& hy_km,
-                                              const Pack<T, V>& hx_jm, const Pack<T, V>& hz_jm, T hy_l, T hz_l,
-                                              const Pack<T, V>& xc, T cy, T cz,
-                                              bool row_lt, bool row_in, bool pl_lt, bool pl_in, bool first) {
-    if (row_lt && pl_in) pair_axpy<-1, T, V>(dx, cz, diff<T, V>(hy, hy_km), false);
-    if (pl_in && row_in) pair_axpy<+1, T, V>(dx, cy, diff<T, V>(hz, hz_jm), false);
-    if (row_lt) {
-        if (pl_in) {
-            pair_axpy<+1, T, V>(dy, cz, diff<T, V>(hx, hx_km), first);
-            pair_axpy_x<-1, T, V>(dy, xc, diff_back_x<T, V>(hz, hz_l));
-        }
+// One term along an axis whose zone is the same for the whole wave (y: the wave's row, z: the plane of this iteration):
+// the plain update between the CPML layers, or inside them  phi = b*phi + a*curl;  d +- (C*curl + dt*phi)
+// (FDTD3D.cpp:545-548 pattern) with the state handed in and out through `ph`.  `t` points at the (b, a, C) tables
+// of this layer on the low side of the axis; the high side follows 6 tables further.
+template <int SIGN, typename T, int V>
+__device__ __forceinline__ void pair_cpml_u(Pack<T, V>& d, const Pack<T, V>& curl, bool skip0, bool high, const T* __restrict__ t, T dt, Pack<T, V>& ph) {
+    const T* tt = t + (high ? 6 * kMaxLayers : 0);
+    const T b = tt[0], a = tt[kMaxLayers], C = tt[2 * kMaxLayers];
+    const T d0 = d.v[0], p0 = ph.v[0];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        const T p = b * ph.v[e] + a * curl.v[e];
+        ph.v[e] = p;
+        const T v = C * curl.v[e] + dt * p;
+        d.v[e] = SIGN > 0 ? d.v[e] + v : d.v[e] - v;
     }
-    if (pl_lt) {
-        if (row_in) {
-            pair_axpy_x<+1, T, V>(dz, xc, diff_back_x<T, V>(hy, hy_l));
-            pair_axpy<-1, T, V>(dz, cy, diff<T, V>(hx, hx_jm), first);
-        }
-    }
+    if (skip0) { ph.v[0] = p0; d.v[0] = d0; }
 }
-// B of plane km from E of the same step at planes km (`e`) and km+1 (`e_kp`), the row above (`ex_jp`, `ez_jp`) and
-// the column to the right (`ey_r`, `ez_r`).
-template <typename T, int V>
-__device__ __forceinline__ void pair_update_b(Pack<T, V>& bx, Pack<T, V>& by, Pack<T, V>& bz,
-                                              const Pack<T, V>* e, const Pack<T, V>* e_kp,
-                                              const Pack<T, V>& ex_jp, const Pack<T, V>& ez_jp, T ey_r, T ez_r,
-                                              const Pack<T, V>& xc, T cy, T cz,
-                                              bool row_lt, bool row_in, bool bl_lt, bool bl_in, bool zk_mid, bool zy_mid, bool first) {
-    if (row_lt && bl_lt) {
-        if (zk_mid) pair_axpy<+1, T, V>(bx, cz, diff<T, V>(e_kp[1], e[1]), first);
-        if (zy_mid) pair_axpy<-1, T, V>(bx, cy, diff<T, V>(ez_jp, e[2]), first);
-    }
-    if (bl_lt && row_in) {
-        pair_axpy_x<+1, T, V>(by, xc, diff_fwd_x<T, V>(e[2], ez_r));
-        if (zk_mid) pair_axpy<-1, T, V>(by, cz, diff<T, V>(e_kp[0], e[0]), false);
-    }
-    if (row_lt && bl_in) {
-        if (zy_mid) pair_axpy<+1, T, V>(bz, cy, diff<T, V>(ex_jp, e[0]), false);
-        pair_axpy_x<-1, T, V>(bz, xc, diff_fwd_x<T, V>(e[1], ey_r));
+// The same along x, where every column has its own (b, a, C)
+template <int SIGN, typename T, int V>
+__device__ __forceinline__ void pair_cpml_x(Pack<T, V>& d, const Pack<T, V>& curl, const Pack<T, V>& b, const Pack<T, V>& a, const Pack<T, V>& C, T dt, Pack<T, V>& ph) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        const T p = b.v[e] * ph.v[e] + a.v[e] * curl.v[e];
+        ph.v[e] = p;
+        const T v = C.v[e] * curl.v[e] + dt * p;
+        d.v[e] = SIGN > 0 ? d.v[e] + v : d.v[e] - v;
     }
 }
 
-template <typename T, bool MU, int V>
+template <typename T, bool MU, bool PML, int V>
 __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_eu(4, 4))) k3_pair(const K3<T> a) {
     static_assert(V <= 2, "the two halo columns on either side must be whole packs");
     constexpr int TW = kLanes * V;                       // columns a wave computes
@@ -122,16 +112,15 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
     const int bx = bid % a.nbx; bid /= a.nbx;
     const int by = bid % a.nby;
     const int bz = bid / a.nby;
-    const int px = a.px, Nx = a.Nx, Ny = a.Ny, Nz = a.Nz;
-    (void)Nx;
+    const int px = a.px, Ny = a.Ny, Nz = a.Nz;
     const int c0 = bx * XS;
-    const int i0 = c0 + (int)lo;
-    const bool live = i0 < px;
+    const bool live = c0 + (int)lo < px;
     // lanes past the end of the row (last x tile only) read the row's last pack instead: whatever they compute is
     // neither stored nor seen by a live lane (the column right of the last stored one is the wall: zero, below)
     const unsigned lc = live ? lo : (unsigned)(px - V - c0);
+    const int i0 = c0 + (int)lc;
     const bool own_x = live && (bx == 0 || i0 >= c0 + 2) && i0 + V <= c0 + TW - 2;
-    const bool wall_r = i0 + V >= px;
+    const bool wall_r = c0 + (int)lo + V >= px;
     const bool first = i0 == 0;
     const int jr = by * (W - 3) - 1 + w;
     const bool row_ok = jr >= 0 && jr < a.ny1;
@@ -139,25 +128,128 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
     const bool own = own_x && row_ok && w >= 1 && w < W - 2;
     const int kb = a.kl0 + bz * a.chunk, ke = min(kb + a.chunk, a.kl1);
     const size_t sz = (size_t)a.ny1 * px;
-    const bool row_lt = j < Ny, row_in = j >= 1 && j < Ny, zy_mid_h = j <= Ny - 2;
-    const T cy = a.dtd[1], cz = a.dtd[2];
+    const bool row_lt = j < Ny, row_in = j >= 1 && j < Ny;
+    const T cy = a.dtd[1], cz = a.dtd[2], dt = a.dt;
+    int lye, lyh;
+    const int zye = zone_e(j, Ny, a.np[1][0], a.np[1][1], lye);
+    const int zyh = zone_h(j, Ny, a.np[1][0], a.np[1][1], true, lyh);
+    const T* face_y = a.tab + (size_t)(1 * 2) * 6 * kMaxLayers;
+    const T* face_z = a.tab + (size_t)(2 * 2) * 6 * kMaxLayers;
+    const bool in_n = PML && a.np[0][0] > 0 && i0 < a.xwn;
+    const bool in_p = PML && a.np[0][1] > 0 && i0 >= a.xp0 && i0 < a.xp0 + a.xwp;
 
-    // LDS: [2][TW] x coefficients (D side, B side); then three regions [2 planes][W rows][2 comps][TW]:
-    // E1 (x, z) for the row below, H1 (x, z) for the row above, E2 (x, z) for the row below
+    // LDS: [6][TW] x coefficients (b, a, C of the D side, then of the B side); then three regions
+    // [2 planes][W rows][2 comps][TW]: E1 (x, z) for the row below, H1 (x, z) for the row above, E2 (x, z) for the row below
     T* const xs = smem;
     const size_t region = (size_t)2 * W * 2 * TW;
-    T* const e1s = smem + 2 * TW;
+    T* const e1s = smem + 6 * TW;
     T* const h1s = e1s + region;
     T* const e2s = h1s + region;
-    if (w < 2) lds_st<T, V>(xs + (size_t)w * TW + lo, ldg<T, V>(a.xrow + (size_t)(w == 0 ? 2 : 5) * px + c0, lc));
+    for (int q = w; q < 6; q += W) lds_st<T, V>(xs + (size_t)q * TW + lo, ldg<T, V>(a.xrow + (size_t)q * px + c0, lc));
     __syncthreads();
-    const P xcd = lds_ld<T, V>(xs + lo), xch = lds_ld<T, V>(xs + TW + lo);
+    const P xcd = lds_ld<T, V>(xs + 2 * TW + lo), xch = lds_ld<T, V>(xs + 5 * TW + lo);
     auto slot = [&](T* reg, int par, int row) -> T* { return reg + ((size_t)(par * W + row) * 2) * TW + lo; };
     const int w_up = w + 1 < W ? w + 1 : w, w_dn = w >= 1 ? w - 1 : w;
+    // CPML state between the two steps of a cell: 12 terms x 2 planes in flight, private to the wave, in device memory
+    // (only touched inside the layers; the second step reads it back one iteration later, from L2)
+    T* const mid = PML ? a.pair_scr + ((size_t)blockIdx.x * W + w) * 24 * TW : nullptr;
 
     auto h_of = [&](const P& b, const P& m) -> P { return MU ? divide<T, V>(b, m) : divide<T, V>(b, a.mu0); };
     auto left_of_tile = [&](T shifted) -> T { return (lane == 0 && bx == 0) ? (T)0 : shifted; };
     auto right_of_tile = [&](T shifted) -> T { return wall_r ? (T)0 : shifted; };
+
+    // ---- the two kinds of term.  step 0: state from the old buffers into `mid`; step 1: from `mid` into the new buffers.
+    // zone-uniform axis (y, z): `off_n`/`off_p` = uniform offsets of the wave's segment in the low / high face arrays
+    auto uterm = [&](auto sign, P& d, const P& curl, bool skip0, int zone, int l, const T* face, int kb3, T cmid,
+                     int step, Slots<T> src, Slots<T> dst, size_t off_n, size_t off_p, int term, int mpar, bool st) {
+        constexpr int SIGN = decltype(sign)::value;
+        if (zone == Z_NONE) return;
+        if (!PML || zone == Z_MID) { pair_axpy<SIGN, T, V>(d, cmid, curl, skip0); return; }
+        if constexpr (PML) {
+            const int side = zone == Z_POS;
+            const size_t off = side ? off_p : off_n;
+            T* const m = mid + (size_t)(mpar * 12 + term) * TW;
+            P ph = step == 0 ? ldg<T, V>(src[side] + off, lc) : ldg<T, V>(m, lo);
+            pair_cpml_u<SIGN, T, V>(d, curl, skip0, side != 0, face + kb3 * kMaxLayers + l, dt, ph);
+            if (step == 0) stg<T, V>(m, lo, ph);
+            else if (st) stg<T, V>(dst[side] + off, lo, ph);
+        }
+    };
+    // x: kb3 = 0 for the D side, 3 for the B side; `off_n`/`off_p` = uniform offsets in the low / high strip arrays
+    auto xterm = [&](auto sign, P& d, const P& curl, int kb3, const P& xc, int step, Slots<T> src, Slots<T> dst,
+                     size_t off_n, ptrdiff_t off_p, int term, int mpar, bool st) {
+        constexpr int SIGN = decltype(sign)::value;
+        if (PML && (in_n || in_p)) {
+            if constexpr (PML) {
+                const P b = lds_ld<T, V>(xs + (size_t)kb3 * TW + lo), aa = lds_ld<T, V>(xs + (size_t)(kb3 + 1) * TW + lo);
+                T* const m = mid + (size_t)(mpar * 12 + term) * TW;
+                P ph;
+                if (step == 0) ph = in_n ? ldg<T, V>(src[0] + off_n, lc) : ldg<T, V>(src[1] + off_p, lc);
+                else ph = ldg<T, V>(m, lo);
+                pair_cpml_x<SIGN, T, V>(d, curl, b, aa, xc, dt, ph);
+                if (step == 0) stg<T, V>(m, lo, ph);
+                else if (st) { if (in_n) stg<T, V>(dst[0] + off_n, lc, ph); else stg<T, V>(dst[1] + off_p, lc, ph); }
+            }
+        } else {
+            pair_axpy_x<SIGN, T, V>(d, xc, curl);
+        }
+    };
+    using Plus = std::integral_constant<int, +1>;
+    using Minus = std::integral_constant<int, -1>;
+
+    // D of plane (kp local, k global) from H of the same step: terms, order and index ranges of k3_fused
+    auto update_d = [&](P* dd, const P& hx, const P& hy, const P& hz, const P& hx_m, const P& hy_m, const P& hx_jm, const P& hz_jm,
+                        T hy_l, T hz_l, int kp, int k, int step, int mpar, bool st) {
+        int lke;
+        const int zke = zone_e(k, Nz, a.np[2][0], a.np[2][1], lke);
+        const bool pl_lt = k >= 0 && k < Nz, pl_in = k >= 1 && k < Nz;
+        const int kpc = kp < a.nzp ? kp : a.nzp - 1;
+        const size_t oz = ((size_t)lke * a.ny1 + j) * px + c0;
+        const size_t oy0 = ((size_t)kpc * a.np[1][0] + lye) * px + c0, oy1 = ((size_t)kpc * a.np[1][1] + lye) * px + c0;
+        const size_t oxn = ((size_t)kpc * a.ny1 + j) * a.xwn + c0;
+        const ptrdiff_t oxp = (ptrdiff_t)(((size_t)kpc * a.ny1 + j) * a.xwp) + (c0 - a.xp0);
+        if (row_lt) uterm(Minus{}, dd[0], diff<T, V>(hy, hy_m), false, zke, lke, face_z, 0, cz, step, ap->phE[0][2], ap->phEn[0][2], oz, oz, 0, mpar, st);
+        if (pl_in) uterm(Plus{}, dd[0], diff<T, V>(hz, hz_jm), false, zye, lye, face_y, 0, cy, step, ap->phE[0][1], ap->phEn[0][1], oy0, oy1, 1, mpar, st);
+        if (((a.src_on >> step) & 1) && k == a.kJ) {
+            const P m = ldg<T, V>(a.mag + (size_t)j * px + c0, lc);
+            const T jx = step == 0 ? a.jx : a.jx2;
+#pragma unroll
+            for (int e = 0; e < V; ++e) dd[0].v[e] = dd[0].v[e] + jx * m.v[e];
+        }
+        if (row_lt) {
+            uterm(Plus{}, dd[1], diff<T, V>(hx, hx_m), first, zke, lke, face_z, 0, cz, step, ap->phE[1][2], ap->phEn[1][2], oz, oz, 2, mpar, st);
+            if (pl_in) xterm(Minus{}, dd[1], diff_back_x<T, V>(hz, hz_l), 0, xcd, step, ap->phE[1][0], ap->phEn[1][0], oxn, oxp, 3, mpar, st);
+        }
+        if (pl_lt) {
+            if (row_in) xterm(Plus{}, dd[2], diff_back_x<T, V>(hy, hy_l), 0, xcd, step, ap->phE[2][0], ap->phEn[2][0], oxn, oxp, 4, mpar, st);
+            uterm(Minus{}, dd[2], diff<T, V>(hx, hx_jm), first, zye, lye, face_y, 0, cy, step, ap->phE[2][1], ap->phEn[2][1], oy0, oy1, 5, mpar, st);
+        }
+    };
+    // B of plane (kp local, km global) from E of the same step at planes km (`e`) and km+1 (`e_kp`), the row above
+    // (`ex_jp`, `ez_jp`) and the column to the right (`ey_r`, `ez_r`)
+    auto update_b = [&](P* bb, const P* e, const P* e_kp, const P& ex_jp, const P& ez_jp, T ey_r, T ez_r,
+                        int kp, int km, int step, int mpar, bool st) {
+        int lkh;
+        const int zkh = zone_h(km, Nz, a.np[2][0], a.np[2][1], true, lkh);
+        const bool bl_lt = km >= 0 && km < Nz, bl_in = km >= 1 && km < Nz;
+        const int kpc = kp < 0 ? 0 : (kp < a.nzp ? kp : a.nzp - 1);
+        const size_t pz = ((size_t)lkh * a.ny1 + j) * px + c0;
+        const size_t py0 = ((size_t)kpc * a.np[1][0] + lyh) * px + c0, py1 = ((size_t)kpc * a.np[1][1] + lyh) * px + c0;
+        const size_t pxn = ((size_t)kpc * a.ny1 + j) * a.xwn + c0;
+        const ptrdiff_t pxp = (ptrdiff_t)(((size_t)kpc * a.ny1 + j) * a.xwp) + (c0 - a.xp0);
+        if (row_lt && bl_lt) {
+            uterm(Plus{}, bb[0], diff<T, V>(e_kp[1], e[1]), first, zkh, lkh, face_z, 3, cz, step, ap->phM[0][2], ap->phMn[0][2], pz, pz, 6, mpar, st);
+            uterm(Minus{}, bb[0], diff<T, V>(ez_jp, e[2]), first, zyh, lyh, face_y, 3, cy, step, ap->phM[0][1], ap->phMn[0][1], py0, py1, 7, mpar, st);
+        }
+        if (bl_lt && row_in) {
+            xterm(Plus{}, bb[1], diff_fwd_x<T, V>(e[2], ez_r), 3, xch, step, ap->phM[1][0], ap->phMn[1][0], pxn, pxp, 8, mpar, st);
+            uterm(Minus{}, bb[1], diff<T, V>(e_kp[0], e[0]), false, zkh, lkh, face_z, 3, cz, step, ap->phM[1][2], ap->phMn[1][2], pz, pz, 9, mpar, st);
+        }
+        if (row_lt && bl_in) {
+            uterm(Plus{}, bb[2], diff<T, V>(ex_jp, e[0]), false, zyh, lyh, face_y, 3, cy, step, ap->phM[2][1], ap->phMn[2][1], py0, py1, 10, mpar, st);
+            xterm(Minus{}, bb[2], diff_fwd_x<T, V>(e[1], ey_r), 3, xch, step, ap->phM[2][0], ap->phMn[2][0], pxn, pxp, 11, mpar, st);
+        }
+    };
 
     // H0 of the plane below the first one visited
     P hx_km = zero_pack<T, V>(), hy_km = zero_pack<T, V>();
@@ -179,7 +271,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
         asm volatile("" : "+s"(ap));
         const int klc = kl < a.nzp ? kl : a.nzp - 1;          // iterations past the last plane only drain the pipeline
         const size_t ro = ((size_t)klc * a.ny1 + j) * px + c0;
-        const int k = kl + a.zoff, km = k - 1, km2 = k - 2;
+        const int k = kl + a.zoff;
         const int par = kl & 1;
 
         // ------------------------------------------------------------ A: D1(k), E1(k)
@@ -205,14 +297,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
         if (j >= 1) { hx_jm = h_of(b0j, m0j); hz_jm = h_of(b2j, m2j); }
         {
             const T hy_l = left_of_tile(__shfl_up(hy.v[V - 1], 1)), hz_l = left_of_tile(__shfl_up(hz.v[V - 1], 1));
-            const bool pl_lt = k >= 0 && k < Nz, pl_in = k >= 1 && k < Nz;
-            pair_update_d<T, V>(d1[0], d1[1], d1[2], hx, hy, hz, hx_km, hy_km, hx_jm, hz_jm, hy_l, hz_l, xcd, cy, cz,
-                                row_lt, row_in, pl_lt, pl_in, first);
-            if ((a.src_on & 1) && k == a.kJ) {
-                const P m = ldg<T, V>(a.mag + (size_t)j * px + c0, lc);
-#pragma unroll
-                for (int e = 0; e < V; ++e) d1[0].v[e] = d1[0].v[e] + a.jx * m.v[e];
-            }
+            update_d(d1, hx, hy, hz, hx_km, hy_km, hx_jm, hz_jm, hy_l, hz_l, kl, k, 0, par, false);
         }
         P e1[3];
 #pragma unroll
@@ -227,9 +312,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             const T* up = slot(e1s, par ^ 1, w_up);              // E1(k-1) of the row above, published one iteration ago
             const P ex_jp = lds_ld<T, V>(up), ez_jp = lds_ld<T, V>(up + TW);
             const T ey_r = right_of_tile(__shfl_down(e1_km[1].v[0], 1)), ez_r = right_of_tile(__shfl_down(e1_km[2].v[0], 1));
-            const bool bl_lt = km >= 0 && km < Nz, bl_in = km >= 1 && km < Nz, zk_mid = km >= 0 && km <= Nz - 2;
-            pair_update_b<T, V>(b1[0], b1[1], b1[2], e1_km, e1, ex_jp, ez_jp, ey_r, ez_r, xch, cy, cz,
-                                row_lt, row_in, bl_lt, bl_in, zk_mid, zy_mid_h, first);
+            update_b(b1, e1_km, e1, ex_jp, ez_jp, ey_r, ez_r, kl - 1, k - 1, 0, par ^ 1, false);
 #pragma unroll
             for (int c = 0; c < 3; ++c) h1[c] = h_of(b1[c], mu_km[c]);
             lds_st<T, V>(slot(h1s, par, w), h1[0]); lds_st<T, V>(slot(h1s, par, w) + TW, h1[2]);
@@ -246,20 +329,15 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             P hx_jm1 = lds_ld<T, V>(dn), hz_jm1 = lds_ld<T, V>(dn + TW);
             if (j < 1) { hx_jm1 = zero_pack<T, V>(); hz_jm1 = zero_pack<T, V>(); }
             const T hy_l = left_of_tile(__shfl_up(h1[1].v[V - 1], 1)), hz_l = left_of_tile(__shfl_up(h1[2].v[V - 1], 1));
-            const bool pl_lt = km >= 0 && km < Nz, pl_in = km >= 1 && km < Nz;
+            const int km = k - 1;
+            const bool st = own && kl - 1 < ke;
             P d2[3] = {d1_km[0], d1_km[1], d1_km[2]};
-            pair_update_d<T, V>(d2[0], d2[1], d2[2], h1[0], h1[1], h1[2], h1_km2[0], h1_km2[1], hx_jm1, hz_jm1, hy_l, hz_l, xcd, cy, cz,
-                                row_lt, row_in, pl_lt, pl_in, first);
-            if ((a.src_on & 2) && km == a.kJ) {
-                const P m = ldg<T, V>(a.mag + (size_t)j * px + c0, lc);
-#pragma unroll
-                for (int e = 0; e < V; ++e) d2[0].v[e] = d2[0].v[e] + a.jx2 * m.v[e];
-            }
-            if (own && kl - 1 < ke) {
+            update_d(d2, h1[0], h1[1], h1[2], h1_km2[0], h1_km2[1], hx_jm1, hz_jm1, hy_l, hz_l, kl - 1, km, 1, par ^ 1, st);
+            if (st) {
                 const size_t rs = ro - sz * (size_t)(klc - (kl - 1));
                 stg_nt<T, V>(ap->Dn[0] + rs, lo, d2[0]);
                 if (row_lt) stg_nt<T, V>(ap->Dn[1] + rs, lo, d2[1]);
-                if (pl_lt) stg_nt<T, V>(ap->Dn[2] + rs, lo, d2[2]);
+                if (km >= 0 && km < Nz) stg_nt<T, V>(ap->Dn[2] + rs, lo, d2[2]);
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) e2[c] = divide<T, V>(d2[c], ep_km[c]);
@@ -271,10 +349,10 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             const T* up = slot(e2s, par ^ 1, w_up);              // E2(k-2) of the row above, published one iteration ago
             const P ex_jp = lds_ld<T, V>(up), ez_jp = lds_ld<T, V>(up + TW);
             const T ey_r = right_of_tile(__shfl_down(e2_km2[1].v[0], 1)), ez_r = right_of_tile(__shfl_down(e2_km2[2].v[0], 1));
-            const bool bl_lt = km2 >= 0 && km2 < Nz, bl_in = km2 >= 1 && km2 < Nz, zk_mid = km2 >= 0 && km2 <= Nz - 2;
+            const int km2 = k - 2;
+            const bool bl_lt = km2 >= 0 && km2 < Nz;
             P b2[3] = {b1_km2[0], b1_km2[1], b1_km2[2]};
-            pair_update_b<T, V>(b2[0], b2[1], b2[2], e2_km2, e2, ex_jp, ez_jp, ey_r, ez_r, xch, cy, cz,
-                                row_lt, row_in, bl_lt, bl_in, zk_mid, zy_mid_h, first);
+            update_b(b2, e2_km2, e2, ex_jp, ez_jp, ey_r, ez_r, kl - 2, km2, 1, par, own);
             if (own) {
                 const size_t rs = ro - sz * (size_t)(klc - (kl - 2));
                 if (row_lt && bl_lt) stg_nt<T, V>(ap->Bn[0] + rs, lo, b2[0]);

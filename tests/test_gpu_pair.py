@@ -6,7 +6,7 @@ import fdtd_amd
 from fdtd_amd.engine import MODE_FUSED
 from oracle import pyoracle as po
 from tests import util
-from tests.test_gpu_parity import engine3d_from_meta
+from tests.test_gpu_parity import FIX3D, engine3d_from_meta
 
 pytestmark = pytest.mark.gpu
 
@@ -47,6 +47,77 @@ def test_pairs_equal_reference_cavity(prec, rows, chunk):
         ref = util.run_snapshots(tw, meta, outs)
     for key in outs:
         util.assert_equal_arrays(got[key], ref[key], f"cavity pairs fp{prec} step {key[0]} array {key[1]}")
+
+
+@pytest.mark.parametrize("name", FIX3D)
+@pytest.mark.parametrize("prec", [32, 64])
+@pytest.mark.parametrize("rows,chunk", [(16, 48), (6, 2), (9, 5)])
+def test_pairs_equal_reference_3d(name, prec, rows, chunk):
+    """Every 3-D fixture (CPML on all, some or no faces): fp64 against the reference's vectors, fp32 against the
+    fp32 twin, bit for bit, fields and CPML state."""
+    meta, ins, outs, _ = util.load_fixture(name)
+    eng = engine3d_from_meta(meta, prec, mode=MODE_FUSED)
+    eng.pair_shape(chunk, rows)
+    util.feed(eng, ins)
+    got = util.run_snapshots(Paired(eng), meta, outs)
+    if prec == 64:
+        ref = outs
+    else:
+        tw = util.twin3d_from_meta(meta, 32)
+        util.feed(tw, ins)
+        ref = util.run_snapshots(tw, meta, outs)
+    for key in outs:
+        util.assert_equal_arrays(got[key], ref[key], f"{name} pairs fp{prec} step {key[0]} array {key[1]}")
+
+
+@pytest.mark.parametrize("prec,N,npml", [
+    (32, (300, 9, 11), (5, 6, 2, 2, 3, 3)),       # three x tiles
+    (32, (260, 20, 6), (3, 20, 1, 0, 0, 2)),      # the boundary between x tiles 1 and 2 (column 250) inside the high CPML strip
+    (32, (130, 40, 9), (20, 20, 20, 16, 4, 4)),   # more rows than a workgroup owns, CPML rows in two row groups
+    (64, (140, 6, 19), (62, 20, 0, 3, 4, 4)),     # fp64 tiles own 60 columns: boundary inside the low strip
+    (64, (12, 33, 9), (4, 4, 4, 4, 4, 4)),
+    (32, (64, 12, 40), (2, 2, 2, 2, 18, 19)),     # nearly every plane in a z layer
+])
+@pytest.mark.parametrize("has_mu", [False, True])
+@pytest.mark.parametrize("rows,chunk", [(16, 48), (6, 2), (11, 3)])
+def test_pairs_with_cpml_equal_twin_ragged(prec, N, npml, has_mu, rows, chunk):
+    K = po.consts()
+    d = (5e-8, 6e-8, 7e-8)
+    dt = 5e-8 / (2 * K["c0"])
+    steps = 24
+    kJ = N[2] // 2
+    rng = np.random.default_rng(13)
+    wf, mag = po.default_source3d(N[0], N[1], steps, d, dt)
+    mag = rng.random(mag.shape)
+    eps = [K["eps0"] * (1 + 3 * rng.random(po.shape3d(po.EPS_X + c, N, npml))) for c in range(3)]
+    mu = [K["mu0"] * (1 + rng.random(po.shape3d(po.MU_X + c, N, npml))) for c in range(3)]
+    tw = po.Twin3D(prec, N, npml, d, dt, K["mu0"], kJ, steps, has_mu)
+    pair = fdtd_amd.Engine3D(N, npml, d, dt, K["mu0"], kJ, steps, precision=prec, mode=MODE_FUSED, has_mu=has_mu)
+    pair.pair_shape(chunk, rows)
+    for be in (tw, pair):
+        for a in range(3):
+            for s in range(2):
+                tabs = po.cpml_face(npml[a * 2 + s], s, d[a], d[a], dt)
+                for k in range(6):
+                    if npml[a * 2 + s]:
+                        be.set(po.tab_id(a, s, k), tabs[k])
+        be.set(po.JX_WF, wf)
+        be.set(po.JX_MAG, mag)
+        for c in range(3):
+            be.set(po.EPS_X + c, eps[c])
+            if has_mu:
+                be.set(po.MU_X + c, mu[c])
+    # pairs, one single step (the buffers change roles an odd number of times), pairs again, then single steps
+    tw.step(0, 6); pair.step_pairs(0, 3)
+    tw.step(6, 1); pair.step(6, 1)
+    for id_ in po.FIELDS3D + po.ALL_PHI3D:
+        if pair.size(id_):
+            util.assert_equal_arrays(pair.get(id_), tw.get(id_), f"N={N} step 7 array {id_}")
+    tw.step(7, 14); pair.step_pairs(7, 7)
+    tw.step(21, 3); pair.step(21, 3)
+    for id_ in po.FIELDS3D + po.ALL_PHI3D:
+        if pair.size(id_):
+            util.assert_equal_arrays(pair.get(id_), tw.get(id_), f"N={N} step 24 array {id_}")
 
 
 @pytest.mark.parametrize("prec,N", [
@@ -97,9 +168,6 @@ def test_pairs_equal_single_steps_ragged(prec, N, has_mu, rows, chunk):
 
 def test_pairs_refuse_what_they_do_not_carry():
     K = po.consts()
-    with_pml = fdtd_amd.Engine3D((16, 16, 16), (2, 2, 0, 0, 0, 0), (1e-7,) * 3, 1e-16, K["mu0"], 4, 3, precision=32, mode=MODE_FUSED)
-    with pytest.raises(fdtd_amd.EngineError, match="CPML"):
-        with_pml.step_pairs(0, 1)
     slab = fdtd_amd.Engine3D((16, 16, 16), (0,) * 6, (1e-7,) * 3, 1e-16, K["mu0"], 4, 3, precision=32, mode=MODE_FUSED, z_range=(0, 8))
     with pytest.raises(fdtd_amd.EngineError, match="whole grid"):
         slab.step_pairs(0, 1)
