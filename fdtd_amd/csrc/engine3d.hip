@@ -252,6 +252,7 @@ struct fdtd3d_engine {
     virtual int fused_part(int n, int part, hipStream_t s) = 0;
     virtual int step_pair(int n, hipStream_t s) = 0;
     virtual int pair_shape(int chunk, int rows) = 0;
+    virtual bool pair_auto() = 0;
     virtual int parity() = 0;
     virtual int fused_top(hipStream_t s) = 0;
     virtual int placement(double* ms, int cap) = 0;
@@ -1205,17 +1206,26 @@ struct Engine3 : fdtd3d_engine {
     }
 
     // ---- two steps per launch (kernels3d_pair.hpp) ----------------------------------------------
-    int wpbp = 16, chunk_pair = 48;
+    int wpbp = 16, chunk_pair = 0;       // 0: chosen per launch from the grid
     int pair_shape(int chunk_, int rows) override {
         if (chunk_ > 0) chunk_pair = chunk_;
         if (rows >= 6 && rows <= 16) wpbp = rows;
         return FDTD_OK;
     }
+    // fdtd3d_step takes its steps two at a time when that is the faster way: a FUSED engine holding the whole grid,
+    // and enough cells that workgroups of 16 waves x long chunks still fill the chip (FDTD_PAIR=0/1 overrides)
+    bool pair_auto() override {
+        if (!fused || d.z_lo != 0 || d.z_hi != d.Nz) return false;
+        if (const char* e = getenv("FDTD_PAIR")) return atoi(e) != 0;
+        return (size_t)d.Nx * d.Ny * d.Nz >= kPairMinCells;
+    }
+    static constexpr size_t kPairMinCells = (size_t)384 * 384 * 384;
     int step_pair(int n, hipStream_t s) override {
         if (!fused) return fail(FDTD_ERR_STATE, "two-step launches need an engine created with FDTD3D_MODE_FUSED");
         if (d.z_lo != 0 || d.z_hi != d.Nz) return fail(FDTD_ERR_STATE, "two-step launches need the whole grid on this device");
         bool pml = false;
         for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) pml = pml || np[ax][sd] != 0;
+        if (getenv("FDTD_PAIR_FORCE_PML")) pml = true;        // experiment: the CPML-capable kernel on a grid without layers
         if (phase != 0) return fail(FDTD_ERR_STATE, "two-step launch in the middle of a split step");
         constexpr int PV = V / 2, TW = kLanes * PV, XS = TW - 4;
         K3<T> a = args();
@@ -1237,7 +1247,13 @@ struct Engine3 : fdtd3d_engine {
         a.nbx = cover > TW - 2 ? (cover - (TW - 2) + XS - 1) / XS + 1 : 1;
         a.wpb = wpbp;
         a.nby = (ny1 + (wpbp - 3) - 1) / (wpbp - 3);
-        a.chunk = chunk_pair;
+        // planes per workgroup: long chunks amortise the three extra iterations of a chunk, but the launch should
+        // still have a few workgroups per CU
+        if (chunk_pair > 0) a.chunk = chunk_pair;
+        else {
+            const int want = (1024 + a.nbx * a.nby - 1) / (a.nbx * a.nby);
+            a.chunk = std::max(8, std::min(96, (nzp - 1 + want - 1) / want));
+        }
         a.kl0 = 1; a.kl1 = nzp;
         a.nbz = (a.kl1 - a.kl0 + a.chunk - 1) / a.chunk;
         a.remap = remap == kRemapAuto ? std::max(2, a.nbx) : remap;
@@ -1357,9 +1373,16 @@ int fdtd3d_fill_array(fdtd3d_handle h, int id, uint64_t seed, double lo, double 
 int fdtd3d_step(fdtd3d_handle h, int n0, int count, void* stream) {
     return entry(h, [&]() -> int {
         if (h->d.z_lo != 0 || h->d.z_hi != h->d.Nz) return fail(FDTD_ERR_STATE, "fdtd3d_step needs the whole grid on this device; slab drivers use fdtd3d_half_e / fdtd3d_half_h or fdtd3d_fused");
-        for (int n = n0; n < n0 + count; ++n) {
+        const bool pairs = h->pair_auto() && h->probe_count() == 0;      // a probe is sampled after every single step
+        for (int n = n0; n < n0 + count;) {
+            if (pairs && n + 2 <= n0 + count) {
+                if (int rc = h->step_pair(n, (hipStream_t)stream)) return rc;
+                n += 2;
+                continue;
+            }
             if (int rc = h->step(n, (hipStream_t)stream)) return rc;
             if (int rc = h->probe_record((hipStream_t)stream)) return rc;
+            ++n;
         }
         return FDTD_OK;
     });

@@ -133,10 +133,10 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
     int lye, lyh;
     const int zye = zone_e(j, Ny, a.np[1][0], a.np[1][1], lye);
     const int zyh = zone_h(j, Ny, a.np[1][0], a.np[1][1], true, lyh);
-    const T* face_y = a.tab + (size_t)(1 * 2) * 6 * kMaxLayers;
-    const T* face_z = a.tab + (size_t)(2 * 2) * 6 * kMaxLayers;
     const bool in_n = PML && a.np[0][0] > 0 && i0 < a.xwn;
     const bool in_p = PML && a.np[0][1] > 0 && i0 >= a.xp0 && i0 < a.xp0 + a.xwp;
+    const bool wave_x = PML && __ballot(in_n || in_p) != 0;                       // some lane of this wave lies in an x strip
+    const bool y_layer_e = PML && (zye == Z_NEG || zye == Z_POS), y_layer_h = PML && (zyh == Z_NEG || zyh == Z_POS);
 
     // LDS: [6][TW] x coefficients (b, a, C of the D side, then of the B side); then three regions
     // [2 planes][W rows][2 comps][TW]: E1 (x, z) for the row below, H1 (x, z) for the row above, E2 (x, z) for the row below
@@ -152,43 +152,63 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
     const int w_up = w + 1 < W ? w + 1 : w, w_dn = w >= 1 ? w - 1 : w;
     // CPML state between the two steps of a cell: 12 terms x 2 planes in flight, private to the wave, in device memory
     // (only touched inside the layers; the second step reads it back one iteration later, from L2)
-    T* const mid = PML ? a.pair_scr + ((size_t)blockIdx.x * W + w) * 24 * TW : nullptr;
+    // (what only the layers need -- array extents, table and scratch pointers -- is read from the argument block
+    // where it is used, not kept in scalar registers through the loop)
+    const unsigned mid_off = (unsigned)(((size_t)blockIdx.x * W + w) * 24 * TW);
+    auto mid_of = [&](int mpar, int term) -> T* { return ap->pair_scr + mid_off + (size_t)(mpar * 12 + term) * TW; };
 
     auto h_of = [&](const P& b, const P& m) -> P { return MU ? divide<T, V>(b, m) : divide<T, V>(b, a.mu0); };
     auto left_of_tile = [&](T shifted) -> T { return (lane == 0 && bx == 0) ? (T)0 : shifted; };
     auto right_of_tile = [&](T shifted) -> T { return wall_r ? (T)0 : shifted; };
 
     // ---- the two kinds of term.  step 0: state from the old buffers into `mid`; step 1: from `mid` into the new buffers.
-    // zone-uniform axis (y, z): `off_n`/`off_p` = uniform offsets of the wave's segment in the low / high face arrays
-    auto uterm = [&](auto sign, P& d, const P& curl, bool skip0, int zone, int l, const T* face, int kb3, T cmid,
-                     int step, Slots<T> src, Slots<T> dst, size_t off_n, size_t off_p, int term, int mpar, bool st) {
+    // Offsets into the CPML arrays are only formed inside the layers (most waves never get there).
+    // zone-uniform axis (1 = y, 2 = z); kpc = local plane of the cell (y-face arrays are [plane][layer][column])
+    auto uterm = [&](auto fast, auto sign, P& d, const P& curl, bool skip0, int zone, int l, int axis, int kb3, T cmid,
+                     int step, Slots<T> src, Slots<T> dst, int kpc, int term, int mpar, bool st) {
         constexpr int SIGN = decltype(sign)::value;
+        constexpr bool FAST = decltype(fast)::value;          // the caller knows that no term of this stage lies in a layer
         if (zone == Z_NONE) return;
-        if (!PML || zone == Z_MID) { pair_axpy<SIGN, T, V>(d, cmid, curl, skip0); return; }
-        if constexpr (PML) {
+        if (FAST || zone == Z_MID) { pair_axpy<SIGN, T, V>(d, cmid, curl, skip0); return; }
+        if constexpr (PML && !FAST) {
             const int side = zone == Z_POS;
-            const size_t off = side ? off_p : off_n;
-            T* const m = mid + (size_t)(mpar * 12 + term) * TW;
+            const size_t off = axis == 2 ? ((size_t)l * ap->ny1 + j) * px + c0 : ((size_t)kpc * ap->np[1][side] + l) * px + c0;
+            const T* face = ap->tab + (size_t)(axis * 2) * 6 * kMaxLayers;
+            T* const m = mid_of(mpar, term);
             P ph = step == 0 ? ldg<T, V>(src[side] + off, lc) : ldg<T, V>(m, lo);
             pair_cpml_u<SIGN, T, V>(d, curl, skip0, side != 0, face + kb3 * kMaxLayers + l, dt, ph);
             if (step == 0) stg<T, V>(m, lo, ph);
             else if (st) stg<T, V>(dst[side] + off, lo, ph);
         }
     };
-    // x: kb3 = 0 for the D side, 3 for the B side; `off_n`/`off_p` = uniform offsets in the low / high strip arrays
-    auto xterm = [&](auto sign, P& d, const P& curl, int kb3, const P& xc, int step, Slots<T> src, Slots<T> dst,
-                     size_t off_n, ptrdiff_t off_p, int term, int mpar, bool st) {
+    // x: kb3 = 0 for the D side, 3 for the B side.  Lanes inside a strip have had their state requested by the caller
+    // (`pre`: from the old buffers in step 0, from `mid` in step 1) so that its latency overlaps other work.
+    auto x_request = [&](int step, Slots<T> src, int kpc, int term, int mpar) -> P {
+        P ph = zero_pack<T, V>();
+        if constexpr (PML) {
+            if (wave_x && (in_n || in_p)) {
+                if (step == 0) {
+                    const size_t row = (size_t)kpc * ap->ny1 + j;
+                    ph = in_n ? ldg<T, V>(src[0] + row * ap->xwn + c0, lc) : ldg<T, V>(src[1] + (ptrdiff_t)(row * ap->xwp) + (c0 - ap->xp0), lc);
+                } else {
+                    ph = ldg<T, V>(mid_of(mpar, term), lo);
+                }
+            }
+        }
+        return ph;
+    };
+    auto xterm = [&](auto fast, auto sign, P& d, const P& curl, int kb3, const P& xc, int step, P ph, Slots<T> dst, int kpc, int term, int mpar, bool st) {
         constexpr int SIGN = decltype(sign)::value;
-        if (PML && (in_n || in_p)) {
-            if constexpr (PML) {
+        constexpr bool FAST = decltype(fast)::value;
+        if (PML && !FAST && (in_n || in_p)) {
+            if constexpr (PML && !FAST) {
                 const P b = lds_ld<T, V>(xs + (size_t)kb3 * TW + lo), aa = lds_ld<T, V>(xs + (size_t)(kb3 + 1) * TW + lo);
-                T* const m = mid + (size_t)(mpar * 12 + term) * TW;
-                P ph;
-                if (step == 0) ph = in_n ? ldg<T, V>(src[0] + off_n, lc) : ldg<T, V>(src[1] + off_p, lc);
-                else ph = ldg<T, V>(m, lo);
                 pair_cpml_x<SIGN, T, V>(d, curl, b, aa, xc, dt, ph);
-                if (step == 0) stg<T, V>(m, lo, ph);
-                else if (st) { if (in_n) stg<T, V>(dst[0] + off_n, lc, ph); else stg<T, V>(dst[1] + off_p, lc, ph); }
+                if (step == 0) stg<T, V>(mid_of(mpar, term), lo, ph);
+                else if (st) {
+                    const size_t row = (size_t)kpc * ap->ny1 + j;
+                    if (in_n) stg<T, V>(dst[0] + row * ap->xwn + c0, lc, ph); else stg<T, V>(dst[1] + (ptrdiff_t)(row * ap->xwp) + (c0 - ap->xp0), lc, ph);
+                }
             }
         } else {
             pair_axpy_x<SIGN, T, V>(d, xc, curl);
@@ -199,56 +219,59 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
 
     // D of plane (kp local, k global) from H of the same step: terms, order and index ranges of k3_fused
     auto update_d = [&](P* dd, const P& hx, const P& hy, const P& hz, const P& hx_m, const P& hy_m, const P& hx_jm, const P& hz_jm,
-                        T hy_l, T hz_l, int kp, int k, int step, int mpar, bool st) {
+                        T hy_l, T hz_l, int kp, int k, int step, int mpar, bool st, const P& pre_y, const P& pre_z) {
         int lke;
         const int zke = zone_e(k, Nz, a.np[2][0], a.np[2][1], lke);
         const bool pl_lt = k >= 0 && k < Nz, pl_in = k >= 1 && k < Nz;
         const int kpc = kp < a.nzp ? kp : a.nzp - 1;
-        const size_t oz = ((size_t)lke * a.ny1 + j) * px + c0;
-        const size_t oy0 = ((size_t)kpc * a.np[1][0] + lye) * px + c0, oy1 = ((size_t)kpc * a.np[1][1] + lye) * px + c0;
-        const size_t oxn = ((size_t)kpc * a.ny1 + j) * a.xwn + c0;
-        const ptrdiff_t oxp = (ptrdiff_t)(((size_t)kpc * a.ny1 + j) * a.xwp) + (c0 - a.xp0);
-        if (row_lt) uterm(Minus{}, dd[0], diff<T, V>(hy, hy_m), false, zke, lke, face_z, 0, cz, step, ap->phE[0][2], ap->phEn[0][2], oz, oz, 0, mpar, st);
-        if (pl_in) uterm(Plus{}, dd[0], diff<T, V>(hz, hz_jm), false, zye, lye, face_y, 0, cy, step, ap->phE[0][1], ap->phEn[0][1], oy0, oy1, 1, mpar, st);
-        if (((a.src_on >> step) & 1) && k == a.kJ) {
-            const P m = ldg<T, V>(a.mag + (size_t)j * px + c0, lc);
-            const T jx = step == 0 ? a.jx : a.jx2;
+        auto terms = [&](auto fast) {
+            if (row_lt) uterm(fast, Minus{}, dd[0], diff<T, V>(hy, hy_m), false, zke, lke, 2, 0, cz, step, ap->phE[0][2], ap->phEn[0][2], kpc, 0, mpar, st);
+            if (pl_in) uterm(fast, Plus{}, dd[0], diff<T, V>(hz, hz_jm), false, zye, lye, 1, 0, cy, step, ap->phE[0][1], ap->phEn[0][1], kpc, 1, mpar, st);
+            if (((a.src_on >> step) & 1) && k == a.kJ) {
+                const P m = ldg<T, V>(a.mag + (size_t)j * px + c0, lc);
+                const T jx = step == 0 ? a.jx : a.jx2;
 #pragma unroll
-            for (int e = 0; e < V; ++e) dd[0].v[e] = dd[0].v[e] + jx * m.v[e];
-        }
-        if (row_lt) {
-            uterm(Plus{}, dd[1], diff<T, V>(hx, hx_m), first, zke, lke, face_z, 0, cz, step, ap->phE[1][2], ap->phEn[1][2], oz, oz, 2, mpar, st);
-            if (pl_in) xterm(Minus{}, dd[1], diff_back_x<T, V>(hz, hz_l), 0, xcd, step, ap->phE[1][0], ap->phEn[1][0], oxn, oxp, 3, mpar, st);
-        }
-        if (pl_lt) {
-            if (row_in) xterm(Plus{}, dd[2], diff_back_x<T, V>(hy, hy_l), 0, xcd, step, ap->phE[2][0], ap->phEn[2][0], oxn, oxp, 4, mpar, st);
-            uterm(Minus{}, dd[2], diff<T, V>(hx, hx_jm), first, zye, lye, face_y, 0, cy, step, ap->phE[2][1], ap->phEn[2][1], oy0, oy1, 5, mpar, st);
-        }
+                for (int e = 0; e < V; ++e) dd[0].v[e] = dd[0].v[e] + jx * m.v[e];
+            }
+            if (row_lt) {
+                uterm(fast, Plus{}, dd[1], diff<T, V>(hx, hx_m), first, zke, lke, 2, 0, cz, step, ap->phE[1][2], ap->phEn[1][2], kpc, 2, mpar, st);
+                if (pl_in) xterm(fast, Minus{}, dd[1], diff_back_x<T, V>(hz, hz_l), 0, xcd, step, pre_y, ap->phEn[1][0], kpc, 3, mpar, st);
+            }
+            if (pl_lt) {
+                if (row_in) xterm(fast, Plus{}, dd[2], diff_back_x<T, V>(hy, hy_l), 0, xcd, step, pre_z, ap->phEn[2][0], kpc, 4, mpar, st);
+                uterm(fast, Minus{}, dd[2], diff<T, V>(hx, hx_jm), first, zye, lye, 1, 0, cy, step, ap->phE[2][1], ap->phEn[2][1], kpc, 5, mpar, st);
+            }
+        };
+        // most waves are nowhere near a layer: they take the straight-line code of the kernel without CPML
+        if constexpr (!PML) terms(std::true_type{});
+        else if (!wave_x && !y_layer_e && zke != Z_NEG && zke != Z_POS) terms(std::true_type{});
+        else terms(std::false_type{});
     };
     // B of plane (kp local, km global) from E of the same step at planes km (`e`) and km+1 (`e_kp`), the row above
     // (`ex_jp`, `ez_jp`) and the column to the right (`ey_r`, `ez_r`)
     auto update_b = [&](P* bb, const P* e, const P* e_kp, const P& ex_jp, const P& ez_jp, T ey_r, T ez_r,
-                        int kp, int km, int step, int mpar, bool st) {
+                        int kp, int km, int step, int mpar, bool st, const P& pre_y, const P& pre_z) {
         int lkh;
         const int zkh = zone_h(km, Nz, a.np[2][0], a.np[2][1], true, lkh);
         const bool bl_lt = km >= 0 && km < Nz, bl_in = km >= 1 && km < Nz;
         const int kpc = kp < 0 ? 0 : (kp < a.nzp ? kp : a.nzp - 1);
-        const size_t pz = ((size_t)lkh * a.ny1 + j) * px + c0;
-        const size_t py0 = ((size_t)kpc * a.np[1][0] + lyh) * px + c0, py1 = ((size_t)kpc * a.np[1][1] + lyh) * px + c0;
-        const size_t pxn = ((size_t)kpc * a.ny1 + j) * a.xwn + c0;
-        const ptrdiff_t pxp = (ptrdiff_t)(((size_t)kpc * a.ny1 + j) * a.xwp) + (c0 - a.xp0);
-        if (row_lt && bl_lt) {
-            uterm(Plus{}, bb[0], diff<T, V>(e_kp[1], e[1]), first, zkh, lkh, face_z, 3, cz, step, ap->phM[0][2], ap->phMn[0][2], pz, pz, 6, mpar, st);
-            uterm(Minus{}, bb[0], diff<T, V>(ez_jp, e[2]), first, zyh, lyh, face_y, 3, cy, step, ap->phM[0][1], ap->phMn[0][1], py0, py1, 7, mpar, st);
-        }
-        if (bl_lt && row_in) {
-            xterm(Plus{}, bb[1], diff_fwd_x<T, V>(e[2], ez_r), 3, xch, step, ap->phM[1][0], ap->phMn[1][0], pxn, pxp, 8, mpar, st);
-            uterm(Minus{}, bb[1], diff<T, V>(e_kp[0], e[0]), false, zkh, lkh, face_z, 3, cz, step, ap->phM[1][2], ap->phMn[1][2], pz, pz, 9, mpar, st);
-        }
-        if (row_lt && bl_in) {
-            uterm(Plus{}, bb[2], diff<T, V>(ex_jp, e[0]), false, zyh, lyh, face_y, 3, cy, step, ap->phM[2][1], ap->phMn[2][1], py0, py1, 10, mpar, st);
-            xterm(Minus{}, bb[2], diff_fwd_x<T, V>(e[1], ey_r), 3, xch, step, ap->phM[2][0], ap->phMn[2][0], pxn, pxp, 11, mpar, st);
-        }
+        auto terms = [&](auto fast) {
+            if (row_lt && bl_lt) {
+                uterm(fast, Plus{}, bb[0], diff<T, V>(e_kp[1], e[1]), first, zkh, lkh, 2, 3, cz, step, ap->phM[0][2], ap->phMn[0][2], kpc, 6, mpar, st);
+                uterm(fast, Minus{}, bb[0], diff<T, V>(ez_jp, e[2]), first, zyh, lyh, 1, 3, cy, step, ap->phM[0][1], ap->phMn[0][1], kpc, 7, mpar, st);
+            }
+            if (bl_lt && row_in) {
+                xterm(fast, Plus{}, bb[1], diff_fwd_x<T, V>(e[2], ez_r), 3, xch, step, pre_y, ap->phMn[1][0], kpc, 8, mpar, st);
+                uterm(fast, Minus{}, bb[1], diff<T, V>(e_kp[0], e[0]), false, zkh, lkh, 2, 3, cz, step, ap->phM[1][2], ap->phMn[1][2], kpc, 9, mpar, st);
+            }
+            if (row_lt && bl_in) {
+                uterm(fast, Plus{}, bb[2], diff<T, V>(ex_jp, e[0]), false, zyh, lyh, 1, 3, cy, step, ap->phM[2][1], ap->phMn[2][1], kpc, 10, mpar, st);
+                xterm(fast, Minus{}, bb[2], diff_fwd_x<T, V>(e[1], ey_r), 3, xch, step, pre_z, ap->phMn[2][0], kpc, 11, mpar, st);
+            }
+        };
+        if constexpr (!PML) terms(std::true_type{});
+        else if (!wave_x && !y_layer_h && zkh != Z_NEG && zkh != Z_POS) terms(std::true_type{});
+        else terms(std::false_type{});
     };
 
     // H0 of the plane below the first one visited
@@ -291,13 +314,18 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
         if (MU) { m0j = ldg<T, V>(ap->mu[0] + rj, lc); m2j = ldg<T, V>(ap->mu[2] + rj, lc); }
 #pragma unroll
         for (int c = 0; c < 3; ++c) { d1[c] = ldg<T, V>(ap->D[c] + ro, lc); ep[c] = ldg<T, V>(ap->eps[c] + ro, lc); }
+        // lanes inside an x strip: the old CPML state of this iteration's first-step terms
+        const P xe_y = x_request(0, ap->phE[1][0], klc, 3, par), xe_z = x_request(0, ap->phE[2][0], klc, 4, par);
+        const int klm = kl >= 1 ? (kl - 1 < a.nzp ? kl - 1 : a.nzp - 1) : 0;
+        P xm_y = zero_pack<T, V>(), xm_z = zero_pack<T, V>();
+        if (kl >= kb) { xm_y = x_request(0, ap->phM[1][0], klm, 8, par ^ 1); xm_z = x_request(0, ap->phM[2][0], klm, 11, par ^ 1); }
 
         const P hx = h_of(bo[0], mu_[0]), hy = h_of(bo[1], mu_[1]), hz = h_of(bo[2], mu_[2]);
         P hx_jm = zero_pack<T, V>(), hz_jm = zero_pack<T, V>();
         if (j >= 1) { hx_jm = h_of(b0j, m0j); hz_jm = h_of(b2j, m2j); }
         {
             const T hy_l = left_of_tile(__shfl_up(hy.v[V - 1], 1)), hz_l = left_of_tile(__shfl_up(hz.v[V - 1], 1));
-            update_d(d1, hx, hy, hz, hx_km, hy_km, hx_jm, hz_jm, hy_l, hz_l, kl, k, 0, par, false);
+            update_d(d1, hx, hy, hz, hx_km, hy_km, hx_jm, hz_jm, hy_l, hz_l, kl, k, 0, par, false, xe_y, xe_z);
         }
         P e1[3];
 #pragma unroll
@@ -312,7 +340,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             const T* up = slot(e1s, par ^ 1, w_up);              // E1(k-1) of the row above, published one iteration ago
             const P ex_jp = lds_ld<T, V>(up), ez_jp = lds_ld<T, V>(up + TW);
             const T ey_r = right_of_tile(__shfl_down(e1_km[1].v[0], 1)), ez_r = right_of_tile(__shfl_down(e1_km[2].v[0], 1));
-            update_b(b1, e1_km, e1, ex_jp, ez_jp, ey_r, ez_r, kl - 1, k - 1, 0, par ^ 1, false);
+            update_b(b1, e1_km, e1, ex_jp, ez_jp, ey_r, ez_r, kl - 1, k - 1, 0, par ^ 1, false, xm_y, xm_z);
 #pragma unroll
             for (int c = 0; c < 3; ++c) h1[c] = h_of(b1[c], mu_km[c]);
             lds_st<T, V>(slot(h1s, par, w), h1[0]); lds_st<T, V>(slot(h1s, par, w) + TW, h1[2]);
@@ -323,6 +351,10 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
         P e2[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) e2[c] = zero_pack<T, V>();
+        // lanes inside an x strip: the state their second-step terms left behind one iteration ago
+        P x2e_y = zero_pack<T, V>(), x2e_z = zero_pack<T, V>(), x2m_y = zero_pack<T, V>(), x2m_z = zero_pack<T, V>();
+        if (kl >= kb + 1) { x2e_y = x_request(1, ap->phE[1][0], 0, 3, par ^ 1); x2e_z = x_request(1, ap->phE[2][0], 0, 4, par ^ 1); }
+        if (kl >= kb + 2) { x2m_y = x_request(1, ap->phM[1][0], 0, 8, par); x2m_z = x_request(1, ap->phM[2][0], 0, 11, par); }
         if (kl >= kb + 1) {
             asm volatile("" : "+s"(ap));
             const T* dn = slot(h1s, par, w_dn);                  // H1(k-1) of the row below, published before the barrier
@@ -332,7 +364,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             const int km = k - 1;
             const bool st = own && kl - 1 < ke;
             P d2[3] = {d1_km[0], d1_km[1], d1_km[2]};
-            update_d(d2, h1[0], h1[1], h1[2], h1_km2[0], h1_km2[1], hx_jm1, hz_jm1, hy_l, hz_l, kl - 1, km, 1, par ^ 1, st);
+            update_d(d2, h1[0], h1[1], h1[2], h1_km2[0], h1_km2[1], hx_jm1, hz_jm1, hy_l, hz_l, kl - 1, km, 1, par ^ 1, st, x2e_y, x2e_z);
             if (st) {
                 const size_t rs = ro - sz * (size_t)(klc - (kl - 1));
                 stg_nt<T, V>(ap->Dn[0] + rs, lo, d2[0]);
@@ -352,7 +384,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             const int km2 = k - 2;
             const bool bl_lt = km2 >= 0 && km2 < Nz;
             P b2[3] = {b1_km2[0], b1_km2[1], b1_km2[2]};
-            update_b(b2, e2_km2, e2, ex_jp, ez_jp, ey_r, ez_r, kl - 2, km2, 1, par, own);
+            update_b(b2, e2_km2, e2, ex_jp, ez_jp, ey_r, ez_r, kl - 2, km2, 1, par, own, x2m_y, x2m_z);
             if (own) {
                 const size_t rs = ro - sz * (size_t)(klc - (kl - 2));
                 if (row_lt && bl_lt) stg_nt<T, V>(ap->Bn[0] + rs, lo, b2[0]);

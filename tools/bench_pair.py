@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""One step per launch (k3_fused) against two steps per launch (k3_pair) on a grid without CPML:
-    python tools/bench_pair.py [--n 1024] [--mu 1] [--prec 32] [--steps 20] [--chunk 48] [--rows 16] [--only pair|single]
+"""One step per launch (k3_fused) against two steps per launch (k3_pair) on a whole-grid engine:
+    python tools/bench_pair.py [--n 1024] [--npml 0] [--mu 1] [--prec 32] [--steps 20] [--chunk 48] [--rows 16] [--only pair|single]
 Prints one JSON line; --check compares checksums of D and B after the same number of steps."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,15 +18,19 @@ ap.add_argument("--chunk", type=int, default=0)
 ap.add_argument("--rows", type=int, default=0)
 ap.add_argument("--only", default="")
 ap.add_argument("--check", type=int, default=1)
+ap.add_argument("--npml", default="0", help="layers on every face, or six numbers x-,x+,y-,y+,z-,z+")
 a = ap.parse_args()
+a.npml = tuple(int(v) for v in a.npml.split(",")) if "," in a.npml else (int(a.npml),) * 6
 K = fs.constants(); d = (1053e-9 / 20,) * 3; dt = d[0] / (K["c0"] * 2)
 N = (a.n, a.n, a.nz or a.n)
 cells = N[0] * N[1] * N[2]
-out = {"grid": list(N), "precision": a.prec, "mu_grid": bool(a.mu), "steps": a.steps}
+out = {"grid": list(N), "npml": list(a.npml), "precision": a.prec, "mu_grid": bool(a.mu), "steps": a.steps}
 
 
 def make():
-    eng = fdtd_amd.Engine3D(N, (0,) * 6, d, dt, K["mu0"], N[2] // 2, 4096, precision=a.prec, has_mu=bool(a.mu), mode=E.MODE_FUSED)
+    eng = fdtd_amd.Engine3D(N, a.npml, d, dt, K["mu0"], N[2] // 2, 4096, precision=a.prec, has_mu=bool(a.mu), mode=E.MODE_FUSED)
+    if any(a.npml):
+        fs.load_cpml3d(eng, d, dt)
     wf, mag = fs.default_source3d(N[0], N[1], 4096, d, dt)
     eng.set(E.JX_WF, wf); eng.set(E.JX_MAG, mag)
     eng.fill_materials(1234, K["eps0"], 4 * K["eps0"], K["mu0"], (2 if a.mu else 1) * K["mu0"])
