@@ -98,7 +98,7 @@ def cpu_baseline():
             "sample": f"CPU restatement of the reference loops (fp64), 128^3 with eps/mu grids and 20-layer CPML, {steps} steps in {el:.1f} s"}
 
 
-KIND_NAME = {0: "half_e", 1: "half_h", 2: "fused"}
+KIND_NAME = {0: "half_e", 1: "half_h", 2: "fused", 3: "pair"}
 PART_NAME = {0: "all", 1: "edge", 2: "interior", 3: "top"}
 
 
@@ -108,7 +108,9 @@ def byte_models(has_mu: bool, mode_name: str):
     ref_e, ref_h = 15 * 4, (12 + (3 if has_mu else 0)) * 4
     # fused: D, B read and written once, eps (and mu) read once; lean: D (B) read and written by its own half
     # and read by the other, eps and mu read by both halves; full: the reference's traffic
-    own_words = {"fused": 15 + (3 if has_mu else 0), "lean": 18 + (6 if has_mu else 3), "full": 27 + (3 if has_mu else 0)}[mode_name]
+    # pair: the fused kernel's words once per TWO steps
+    own_words = {"fused": 15 + (3 if has_mu else 0), "pair": (15 + (3 if has_mu else 0)) / 2, "lean": 18 + (6 if has_mu else 3),
+                 "full": 27 + (3 if has_mu else 0)}[mode_name]
     return ref_e, ref_h, own_words * 4
 
 
@@ -143,7 +145,7 @@ def stamped_traffic(eng, mode_name: str, dom: str, applies: bool):
             rec = json.load(f)
         if rec.get("kernel_source_sha256") != kernel_source_digest():
             return None, "kernel sources changed since the PMC pass"
-        if rec.get("launch_shape") != eng.launch_shape():
+        if rec.get("launch_shape") != eng.stamp_shape():
             return None, "launch shape differs from the PMC pass"
         return rec["per_launch"][dom]["total_bytes"], os.path.relpath(path, ROOT)
     except (OSError, KeyError, ValueError):
@@ -155,10 +157,18 @@ def roofline_block(eng, mode_name, has_mu, cells_local, steps, applies_traffic, 
     n_e, ms_e = eng.kernel_time(0)
     n_h, ms_h = eng.kernel_time(1)
     n_f, ms_f = eng.kernel_time(2)
+    n_p, ms_p = eng.kernel_time(3)
+    if n_p > 0:
+        mode_name = "pair"
     ref_e, ref_h, own = byte_models(has_mu, mode_name)
     k = max(steps, 1)
     t_e, t_h, t_f = ms_e / k * 1e-3, ms_h / k * 1e-3, ms_f / k * 1e-3          # device seconds per step per kernel kind
-    if mode_name == "fused":
+    t_p = ms_p / k * 1e-3
+    if mode_name == "pair":
+        # one launch of the two-step kernel is two whole steps of every cell (an odd step count ends with one launch
+        # of the one-step kernel: its time is part of the steps' kernel time)
+        dom, dom_bytes, t_dom, own_bytes = "k3_pair", ref_e + ref_h, t_p + t_f + t_h, own
+    elif mode_name == "fused":
         # per step the fused launches (one; or edge + top + interior on a slab) visit every owned cell once, and on a
         # slab below another one the single-plane H kernel finishes the top layer: all of it is the step's kernel time
         dom, dom_bytes, t_dom, own_bytes = "k3_fused", ref_e + ref_h, t_f + t_h, own
@@ -169,15 +179,18 @@ def roofline_block(eng, mode_name, has_mu, cells_local, steps, applies_traffic, 
     ach = cells_local * dom_bytes / t_dom / 1e9 if t_dom > 0 else 0.0
     own_rate = cells_local * own_bytes / t_dom / 1e9 if t_dom > 0 else 0.0
     traffic, traffic_src = stamped_traffic(eng, mode_name, dom, applies_traffic)
+    spl = 2 if dom == "k3_pair" else 1                    # time steps one launch of the dominant kernel advances
     return {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_src,
-            "traffic_rate_GBs": (traffic / t_dom / 1e9) if (traffic and t_dom > 0) else None,   # bytes really moved per second
-            "traffic_frac_of_peak": (traffic / t_dom / 1e9 / HBM_PEAK_GBS) if (traffic and t_dom > 0) else None,
-            "algorithmic_bytes_per_launch": cells_local * dom_bytes, "algorithmic_bytes_per_cell": dom_bytes,
+            "traffic_rate_GBs": (traffic / (t_dom * spl) / 1e9) if (traffic and t_dom > 0) else None,   # bytes really moved per second
+            "traffic_frac_of_peak": (traffic / (t_dom * spl) / 1e9 / HBM_PEAK_GBS) if (traffic and t_dom > 0) else None,
+            "steps_per_launch": spl,
+            "kernel_ms_per_launch": (ms_p / n_p) if n_p > 0 else None,
+            "algorithmic_bytes_per_launch": cells_local * dom_bytes * spl, "algorithmic_bytes_per_cell": dom_bytes,
             "own_model_bytes_per_cell": own_bytes, "own_model_GBs": own_rate, "own_model_frac": own_rate / HBM_PEAK_GBS,
             "cells_per_launch": cells_local, "kernel_ms_per_step": t_dom * 1e3,
             "ms_per_step_e_half": t_e * 1e3, "ms_per_step_h_half": t_h * 1e3, "ms_per_step_fused": t_f * 1e3,
-            "launches_per_step": {"k3_half_e": n_e / k, "k3_half_h": n_h / k, "k3_fused": n_f / k},
+            "launches_per_step": {"k3_half_e": n_e / k, "k3_half_h": n_h / k, "k3_fused": n_f / k, "k3_pair": n_p / k},
             "whole_step_frac": (total_cells * (ref_e + ref_h) * steps / el / 1e9) / (HBM_PEAK_GBS * world) if el > 0 else 0.0}
 
 
@@ -303,10 +316,11 @@ def main():
             "config": {"workload": f"fdtd3d {Nx}x{Ny}x{Nz} ({Nz // world} layers per GPU), heterogeneous eps"
                                    f"{'/mu' if has_mu else ''} grid, 20-layer CPML on six faces, Gaussian sheet source",
                        "grid": [Nx, Ny, Nz], "cpml_layers": 20, "mu_grid": has_mu, "decomposition": f"z-slabs x{world}",
-                       "storage": {"fused": "D,B resident in two buffer sets; E=D/eps, H=B/mu formed in registers; one kernel per step",
+                       "storage": {"fused": "D,B resident in two buffer sets; E=D/eps, H=B/mu formed in registers; "
+                                            + ("one kernel per TWO steps (k3_pair)" if roof["kernel"] == "k3_pair" else "one kernel per step"),
                                    "lean": "D,B resident; E=D/eps, H=B/mu recomputed in the consuming kernel; two kernels per step",
                                    "full": "D,E,B,H resident; two kernels per step"}[mode_name],
-                       "launch_shape": eng.launch_shape(),
+                       "launch_shape": eng.stamp_shape(),
                        "device_bytes_per_gpu": eng.device_bytes(), "placement_probe_ms": [round(v, 3) for v in eng.placement_probes()],
                        "physical_gap_between_arrays_gib": eng.spread_gap_gib()},
             "roofline": roof,

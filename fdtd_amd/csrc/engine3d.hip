@@ -253,6 +253,7 @@ struct fdtd3d_engine {
     virtual int step_pair(int n, hipStream_t s) = 0;
     virtual int pair_shape(int chunk, int rows) = 0;
     virtual bool pair_auto() = 0;
+    virtual void pair_info(int out[4]) = 0;
     virtual int parity() = 0;
     virtual int fused_top(hipStream_t s) = 0;
     virtual int placement(double* ms, int cap) = 0;
@@ -1220,6 +1221,20 @@ struct Engine3 : fdtd3d_engine {
         return (size_t)d.Nx * d.Ny * d.Nz >= kPairMinCells;
     }
     static constexpr size_t kPairMinCells = (size_t)384 * 384 * 384;
+    int pair_nbx() const {
+        constexpr int TW = kLanes * (V / 2), XS = TW - 4;
+        const int cover = std::min(d.Nx + 1, px);            // columns that hold anything
+        return cover > TW - 2 ? (cover - (TW - 2) + XS - 1) / XS + 1 : 1;
+    }
+    // planes per workgroup: long chunks amortise the three extra iterations of a chunk, but the launch should
+    // still have a few workgroups per CU
+    int pair_chunk() const {
+        if (chunk_pair > 0) return chunk_pair;
+        const int per_layer = pair_nbx() * ((ny1 + (wpbp - 3) - 1) / (wpbp - 3));
+        const int want = (1024 + per_layer - 1) / per_layer;
+        return std::max(8, std::min(96, (nzp - 1 + want - 1) / want));
+    }
+    void pair_info(int out[4]) override { out[0] = pair_auto() ? 1 : 0; out[1] = pair_chunk(); out[2] = wpbp; out[3] = V / 2; }
     int step_pair(int n, hipStream_t s) override {
         if (!fused) return fail(FDTD_ERR_STATE, "two-step launches need an engine created with FDTD3D_MODE_FUSED");
         if (d.z_lo != 0 || d.z_hi != d.Nz) return fail(FDTD_ERR_STATE, "two-step launches need the whole grid on this device");
@@ -1227,7 +1242,7 @@ struct Engine3 : fdtd3d_engine {
         for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) pml = pml || np[ax][sd] != 0;
         if (getenv("FDTD_PAIR_FORCE_PML")) pml = true;        // experiment: the CPML-capable kernel on a grid without layers
         if (phase != 0) return fail(FDTD_ERR_STATE, "two-step launch in the middle of a split step");
-        constexpr int PV = V / 2, TW = kLanes * PV, XS = TW - 4;
+        constexpr int PV = V / 2, TW = kLanes * PV;
         K3<T> a = args();
         const bool s1 = n >= 0 && n < (int)wf.size(), s2 = n + 1 >= 0 && n + 1 < (int)wf.size();
         a.src_on = (s1 ? 1 : 0) | (s2 ? 2 : 0);
@@ -1243,17 +1258,10 @@ struct Engine3 : fdtd3d_engine {
             a.Dn[c] = alt[c]; a.Bn[c] = alt[6 + c];
             for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) { a.phEn[c][ax][sd] = phE2[c][ax][sd]; a.phMn[c][ax][sd] = phM2[c][ax][sd]; }
         }
-        const int cover = std::min(d.Nx + 1, px);            // columns that hold anything
-        a.nbx = cover > TW - 2 ? (cover - (TW - 2) + XS - 1) / XS + 1 : 1;
+        a.nbx = pair_nbx();
         a.wpb = wpbp;
         a.nby = (ny1 + (wpbp - 3) - 1) / (wpbp - 3);
-        // planes per workgroup: long chunks amortise the three extra iterations of a chunk, but the launch should
-        // still have a few workgroups per CU
-        if (chunk_pair > 0) a.chunk = chunk_pair;
-        else {
-            const int want = (1024 + a.nbx * a.nby - 1) / (a.nbx * a.nby);
-            a.chunk = std::max(8, std::min(96, (nzp - 1 + want - 1) / want));
-        }
+        a.chunk = pair_chunk();
         a.kl0 = 1; a.kl1 = nzp;
         a.nbz = (a.kl1 - a.kl0 + a.chunk - 1) / a.chunk;
         a.remap = remap == kRemapAuto ? std::max(2, a.nbx) : remap;
@@ -1394,6 +1402,11 @@ int fdtd3d_step_pairs(fdtd3d_handle h, int n0, int pairs, void* stream) {
             if (int rc = h->step_pair(n0 + 2 * q, (hipStream_t)stream)) return rc;
         return FDTD_OK;
     });
+}
+int fdtd3d_pair_info(fdtd3d_handle h, int out[4]) {
+    if (!h || !out) return fail(FDTD_ERR_ARG, "null argument");
+    h->pair_info(out);
+    return FDTD_OK;
 }
 int fdtd3d_pair_shape(fdtd3d_handle h, int chunk, int rows) { return entry(h, [&] { return h->pair_shape(chunk, rows); }); }
 int fdtd3d_fused(fdtd3d_handle h, int n, int part, void* stream) { return entry(h, [&] { return h->fused_part(n, part, (hipStream_t)stream); }); }

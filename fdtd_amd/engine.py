@@ -39,7 +39,7 @@ def kernel_source_digest() -> str:
     (HBM traffic from a profiler pass) is not quoted next to timings of another."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("common.hpp", "kernels3d.hpp", "kernels3d_fused.hpp", "kernels2d.hpp", "kernels2d_fused.hpp"):
+    for name in ("common.hpp", "kernels3d.hpp", "kernels3d_fused.hpp", "kernels3d_pair.hpp", "kernels2d.hpp", "kernels2d_fused.hpp"):
         with open(os.path.join(_HERE, "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()
@@ -197,6 +197,20 @@ class Engine3D(_Common):
     def step_pairs(self, n0: int, pairs: int = 1, stream=None) -> None:
         """Steps n0 .. n0+2*pairs-1, two per launch (fdtd3d_step_pairs: no CPML, whole grid, FUSED mode, no probes)."""
         _check(lib().fdtd3d_step_pairs(self.h, C.c_int(n0), C.c_int(pairs), _stream_handle(stream)), "fdtd3d_step_pairs")
+
+    def pair_info(self) -> dict:
+        """Whether step() goes two steps per launch on this engine, and the two-step kernel's launch shape."""
+        o = (C.c_int * 4)()
+        _check(lib().fdtd3d_pair_info(self.h, o), "fdtd3d_pair_info")
+        return dict(zip(("used_by_step", "planes_per_group", "rows_per_group", "elements_per_lane"), list(o)))
+
+    def stamp_shape(self) -> dict:
+        """Everything about the launch shapes a profiler pass has to share with a timed run to be quoted beside it."""
+        shape = self.launch_shape()
+        pair = self.pair_info()
+        if pair["used_by_step"]:
+            shape["pair"] = pair
+        return shape
 
     def pair_shape(self, chunk: int = 0, rows: int = 0) -> None:
         _check(lib().fdtd3d_pair_shape(self.h, C.c_int(chunk), C.c_int(rows)), "fdtd3d_pair_shape")

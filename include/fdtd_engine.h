@@ -135,13 +135,18 @@ int fdtd3d_step(fdtd3d_handle h, int n0, int count, void* stream);
 /* Steps n0 .. n0 + 2*pairs - 1 with TWO steps per launch (updateE, updateH, updateE, updateH of
  * FDTD3D.cpp:480-1021 for a cell before its neighbours' second step is due): D, B, eps and mu cross
  * device memory once per two steps; the results are those of 2*pairs calls of the one-step kernel, bit
- * for bit.  Restricted to what the kernel carries so far: FUSED mode, the whole grid on this device,
- * no CPML layers on any face (BASELINE's vacuum-cavity configuration), no probes registered (a probe
- * would have to be sampled between the two steps of a launch).  Anything else is refused with
- * FDTD_ERR_STATE; callers fall back to fdtd3d_step.  fdtd3d_pair_shape sets the planes per workgroup
- * (default 48) and the waves per workgroup (6..16, default 16; three of them are halo rows); 0 keeps. */
+ * for bit, CPML state included.  Restricted to what the kernel carries so far: FUSED mode, the whole
+ * grid on this device, no probes registered (a probe would have to be sampled between the two steps of
+ * a launch).  Anything else is refused with FDTD_ERR_STATE.  fdtd3d_step uses these launches by itself
+ * for as many of its steps as it can when the grid is large enough for them to pay (384^3 cells; the
+ * environment variable FDTD_PAIR=0/1 overrides) and no probe is registered.
+ * fdtd3d_pair_shape sets the planes per workgroup (default: chosen from the grid, at most 96) and the
+ * waves per workgroup (6..16, default 16; three of them are halo rows); 0 keeps. */
 int fdtd3d_step_pairs(fdtd3d_handle h, int n0, int pairs, void* stream);
 int fdtd3d_pair_shape(fdtd3d_handle h, int chunk, int rows);
+/* out = { 1 if fdtd3d_step takes its steps two per launch on this engine, planes per workgroup,
+ *         waves per workgroup, elements per lane } of the two-step kernel. */
+int fdtd3d_pair_info(fdtd3d_handle h, int out[4]);
 
 /* Half steps over a sub-range of the owned layers, for slab drivers that overlap the
  * ghost exchange with the interior update.  part: */

@@ -42,7 +42,7 @@ if args.chunk or args.rows:
 if os.environ.get("FDTD_SHAPE_OUT"):            # for tools/pmc_traffic.py: the launch shape these launches use
     import json
     with open(os.environ["FDTD_SHAPE_OUT"], "w") as f:
-        json.dump(eng.launch_shape(), f)
+        json.dump(eng.stamp_shape(), f)
 eng.step(0, args.steps)
 torch.cuda.synchronize()
 print("done", args.mode, n, args.steps)
