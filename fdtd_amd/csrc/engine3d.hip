@@ -1263,7 +1263,18 @@ struct Engine3 : fdtd3d_engine {
         a.nby = (ny1 + (wpbp - 3) - 1) / (wpbp - 3);
         a.chunk = pair_chunk();
         a.kl0 = 1; a.kl1 = nzp;
-        a.nbz = (a.kl1 - a.kl0 + a.chunk - 1) / a.chunk;
+        // chunks that come near the z layers (within the four planes a chunk looks below itself, the one above) are cut
+        // separately: everything else then runs the loop without z-layer code
+        a.zcut[0] = np[2][0] > 0 ? std::min(np[2][0] + 5, a.kl1) : a.kl0;
+        a.zcut[1] = np[2][1] > 0 ? std::max(a.zcut[0], d.Nz - np[2][1] - 1) : a.kl1;
+        const int len[3] = {a.zcut[0] - a.kl0, a.zcut[1] - a.zcut[0], a.kl1 - a.zcut[1]};
+        int nb[3];
+        for (int q = 0; q < 3; ++q) {
+            a.zchunk[q] = (q == 1 || chunk_pair > 0) ? a.chunk : std::max(1, len[q]);      // a face segment is one chunk unless told otherwise
+            nb[q] = (len[q] + a.zchunk[q] - 1) / a.zchunk[q];
+        }
+        a.znb[0] = nb[0]; a.znb[1] = nb[1];
+        a.nbz = nb[0] + nb[1] + nb[2];
         a.remap = remap == kRemapAuto ? std::max(2, a.nbx) : remap;
         const unsigned nblk = (unsigned)a.nbx * a.nby * a.nbz;
         const size_t lds = ((size_t)6 + (size_t)3 * 2 * wpbp * 2) * TW * sizeof(T);

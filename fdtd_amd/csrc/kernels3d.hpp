@@ -57,6 +57,7 @@ struct K3 {
     // two-step kernel only: dt * wf[n+1]; src_on bit 0 = the first step has a source term, bit 1 = the second
     T jx2;
     T* phMn[3][3][2];  // the B-side CPML state it writes (ping-pong, like phEn)
+    int zcut[2], zchunk[3], znb[2];   // the two-step kernel's three plane segments (kernels3d_pair.hpp)
     T* pair_scr;       // CPML state between the two steps of a launch: [workgroup][wave][2 planes][12 terms][columns of a wave]
 };
 

@@ -30,6 +30,7 @@
 
 namespace fdtd {
 
+// (also used for plain global addresses: a V-element vector access aligned to V elements)
 template <typename T, int V>
 __device__ __forceinline__ Pack<T, V> lds_ld(const T* p) {
     typedef T vec __attribute__((ext_vector_type(V)));
@@ -126,281 +127,348 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
     const bool row_ok = jr >= 0 && jr < a.ny1;
     const int j = jr < 0 ? 0 : (jr < a.ny1 ? jr : a.ny1 - 1);
     const bool own = own_x && row_ok && w >= 1 && w < W - 2;
-    const int kb = a.kl0 + bz * a.chunk, ke = min(kb + a.chunk, a.kl1);
+    // planes [kl0, zcut[0]) | [zcut[0], zcut[1]) | [zcut[1], kl1) are cut into chunks separately, so that the chunks that
+    // touch the z layers are short ones of their own
+    int kb, ke;
+    if (bz < a.znb[0]) { kb = a.kl0 + bz * a.zchunk[0]; ke = min(kb + a.zchunk[0], a.zcut[0]); }
+    else if (bz < a.znb[0] + a.znb[1]) { kb = a.zcut[0] + (bz - a.znb[0]) * a.zchunk[1]; ke = min(kb + a.zchunk[1], a.zcut[1]); }
+    else { kb = a.zcut[1] + (bz - a.znb[0] - a.znb[1]) * a.zchunk[2]; ke = min(kb + a.zchunk[2], a.kl1); }
     const size_t sz = (size_t)a.ny1 * px;
     const bool row_lt = j < Ny, row_in = j >= 1 && j < Ny;
     const T cy = a.dtd[1], cz = a.dtd[2], dt = a.dt;
-    int lye, lyh;
-    const int zye = zone_e(j, Ny, a.np[1][0], a.np[1][1], lye);
-    const int zyh = zone_h(j, Ny, a.np[1][0], a.np[1][1], true, lyh);
-    const bool in_n = PML && a.np[0][0] > 0 && i0 < a.xwn;
-    const bool in_p = PML && a.np[0][1] > 0 && i0 >= a.xp0 && i0 < a.xp0 + a.xwp;
-    const bool wave_x = PML && __ballot(in_n || in_p) != 0;                       // some lane of this wave lies in an x strip
-    const bool y_layer_e = PML && (zye == Z_NEG || zye == Z_POS), y_layer_h = PML && (zyh == Z_NEG || zyh == Z_POS);
-
-    // LDS: [6][TW] x coefficients (b, a, C of the D side, then of the B side); then three regions
-    // [2 planes][W rows][2 comps][TW]: E1 (x, z) for the row below, H1 (x, z) for the row above, E2 (x, z) for the row below
-    T* const xs = smem;
-    const size_t region = (size_t)2 * W * 2 * TW;
-    T* const e1s = smem + 6 * TW;
-    T* const h1s = e1s + region;
-    T* const e2s = h1s + region;
-    for (int q = w; q < 6; q += W) lds_st<T, V>(xs + (size_t)q * TW + lo, ldg<T, V>(a.xrow + (size_t)q * px + c0, lc));
-    __syncthreads();
-    const P xcd = lds_ld<T, V>(xs + 2 * TW + lo), xch = lds_ld<T, V>(xs + 5 * TW + lo);
-    auto slot = [&](T* reg, int par, int row) -> T* { return reg + ((size_t)(par * W + row) * 2) * TW + lo; };
-    const int w_up = w + 1 < W ? w + 1 : w, w_dn = w >= 1 ? w - 1 : w;
-    // CPML state between the two steps of a cell: 12 terms x 2 planes in flight, private to the wave, in device memory
-    // (only touched inside the layers; the second step reads it back one iteration later, from L2)
-    // (what only the layers need -- array extents, table and scratch pointers -- is read from the argument block
-    // where it is used, not kept in scalar registers through the loop)
-    const unsigned mid_off = (unsigned)(((size_t)blockIdx.x * W + w) * 24 * TW);
-    auto mid_of = [&](int mpar, int term) -> T* { return ap->pair_scr + mid_off + (size_t)(mpar * 12 + term) * TW; };
-
-    auto h_of = [&](const P& b, const P& m) -> P { return MU ? divide<T, V>(b, m) : divide<T, V>(b, a.mu0); };
-    auto left_of_tile = [&](T shifted) -> T { return (lane == 0 && bx == 0) ? (T)0 : shifted; };
-    auto right_of_tile = [&](T shifted) -> T { return wall_r ? (T)0 : shifted; };
-
-    // ---- the two kinds of term.  step 0: state from the old buffers into `mid`; step 1: from `mid` into the new buffers.
-    // Offsets into the CPML arrays are only formed inside the layers (most waves never get there).
-    // zone-uniform axis (1 = y, 2 = z); kpc = local plane of the cell (y-face arrays are [plane][layer][column])
-    auto uterm = [&](auto fast, auto sign, P& d, const P& curl, bool skip0, int zone, int l, int axis, int kb3, T cmid,
-                     int step, Slots<T> src, Slots<T> dst, int kpc, int term, int mpar, bool st) {
-        constexpr int SIGN = decltype(sign)::value;
-        constexpr bool FAST = decltype(fast)::value;          // the caller knows that no term of this stage lies in a layer
-        if (zone == Z_NONE) return;
-        if (FAST || zone == Z_MID) { pair_axpy<SIGN, T, V>(d, cmid, curl, skip0); return; }
-        if constexpr (PML && !FAST) {
-            const int side = zone == Z_POS;
-            const size_t off = axis == 2 ? ((size_t)l * ap->ny1 + j) * px + c0 : ((size_t)kpc * ap->np[1][side] + l) * px + c0;
-            const T* face = ap->tab + (size_t)(axis * 2) * 6 * kMaxLayers;
-            T* const m = mid_of(mpar, term);
-            P ph = step == 0 ? ldg<T, V>(src[side] + off, lc) : ldg<T, V>(m, lo);
-            pair_cpml_u<SIGN, T, V>(d, curl, skip0, side != 0, face + kb3 * kMaxLayers + l, dt, ph);
-            if (step == 0) stg<T, V>(m, lo, ph);
-            else if (st) stg<T, V>(dst[side] + off, lo, ph);
-        }
-    };
-    // x: kb3 = 0 for the D side, 3 for the B side.  Lanes inside a strip have had their state requested by the caller
-    // (`pre`: from the old buffers in step 0, from `mid` in step 1) so that its latency overlaps other work.
-    auto x_request = [&](int step, Slots<T> src, int kpc, int term, int mpar) -> P {
-        P ph = zero_pack<T, V>();
-        if constexpr (PML) {
-            if (wave_x && (in_n || in_p)) {
-                if (step == 0) {
-                    const size_t row = (size_t)kpc * ap->ny1 + j;
-                    ph = in_n ? ldg<T, V>(src[0] + row * ap->xwn + c0, lc) : ldg<T, V>(src[1] + (ptrdiff_t)(row * ap->xwp) + (c0 - ap->xp0), lc);
-                } else {
-                    ph = ldg<T, V>(mid_of(mpar, term), lo);
-                }
-            }
-        }
-        return ph;
-    };
-    auto xterm = [&](auto fast, auto sign, P& d, const P& curl, int kb3, const P& xc, int step, P ph, Slots<T> dst, int kpc, int term, int mpar, bool st) {
-        constexpr int SIGN = decltype(sign)::value;
-        constexpr bool FAST = decltype(fast)::value;
-        if (PML && !FAST && (in_n || in_p)) {
-            if constexpr (PML && !FAST) {
-                const P b = lds_ld<T, V>(xs + (size_t)kb3 * TW + lo), aa = lds_ld<T, V>(xs + (size_t)(kb3 + 1) * TW + lo);
-                pair_cpml_x<SIGN, T, V>(d, curl, b, aa, xc, dt, ph);
-                if (step == 0) stg<T, V>(mid_of(mpar, term), lo, ph);
-                else if (st) {
-                    const size_t row = (size_t)kpc * ap->ny1 + j;
-                    if (in_n) stg<T, V>(dst[0] + row * ap->xwn + c0, lc, ph); else stg<T, V>(dst[1] + (ptrdiff_t)(row * ap->xwp) + (c0 - ap->xp0), lc, ph);
-                }
-            }
-        } else {
-            pair_axpy_x<SIGN, T, V>(d, xc, curl);
-        }
-    };
-    using Plus = std::integral_constant<int, +1>;
-    using Minus = std::integral_constant<int, -1>;
-
-    // D of plane (kp local, k global) from H of the same step: terms, order and index ranges of k3_fused
-    auto update_d = [&](P* dd, const P& hx, const P& hy, const P& hz, const P& hx_m, const P& hy_m, const P& hx_jm, const P& hz_jm,
-                        T hy_l, T hz_l, int kp, int k, int step, int mpar, bool st, const P& pre_y, const P& pre_z) {
-        int lke;
-        const int zke = zone_e(k, Nz, a.np[2][0], a.np[2][1], lke);
-        const bool pl_lt = k >= 0 && k < Nz, pl_in = k >= 1 && k < Nz;
-        const int kpc = kp < a.nzp ? kp : a.nzp - 1;
-        auto terms = [&](auto fast) {
-            if (row_lt) uterm(fast, Minus{}, dd[0], diff<T, V>(hy, hy_m), false, zke, lke, 2, 0, cz, step, ap->phE[0][2], ap->phEn[0][2], kpc, 0, mpar, st);
-            if (pl_in) uterm(fast, Plus{}, dd[0], diff<T, V>(hz, hz_jm), false, zye, lye, 1, 0, cy, step, ap->phE[0][1], ap->phEn[0][1], kpc, 1, mpar, st);
-            if (((a.src_on >> step) & 1) && k == a.kJ) {
-                const P m = ldg<T, V>(a.mag + (size_t)j * px + c0, lc);
-                const T jx = step == 0 ? a.jx : a.jx2;
-#pragma unroll
-                for (int e = 0; e < V; ++e) dd[0].v[e] = dd[0].v[e] + jx * m.v[e];
-            }
-            if (row_lt) {
-                uterm(fast, Plus{}, dd[1], diff<T, V>(hx, hx_m), first, zke, lke, 2, 0, cz, step, ap->phE[1][2], ap->phEn[1][2], kpc, 2, mpar, st);
-                if (pl_in) xterm(fast, Minus{}, dd[1], diff_back_x<T, V>(hz, hz_l), 0, xcd, step, pre_y, ap->phEn[1][0], kpc, 3, mpar, st);
-            }
-            if (pl_lt) {
-                if (row_in) xterm(fast, Plus{}, dd[2], diff_back_x<T, V>(hy, hy_l), 0, xcd, step, pre_z, ap->phEn[2][0], kpc, 4, mpar, st);
-                uterm(fast, Minus{}, dd[2], diff<T, V>(hx, hx_jm), first, zye, lye, 1, 0, cy, step, ap->phE[2][1], ap->phEn[2][1], kpc, 5, mpar, st);
-            }
-        };
-        // most waves are nowhere near a layer: they take the straight-line code of the kernel without CPML
-        if constexpr (!PML) terms(std::true_type{});
-        else if (!wave_x && !y_layer_e && zke != Z_NEG && zke != Z_POS) terms(std::true_type{});
-        else terms(std::false_type{});
-    };
-    // B of plane (kp local, km global) from E of the same step at planes km (`e`) and km+1 (`e_kp`), the row above
-    // (`ex_jp`, `ez_jp`) and the column to the right (`ey_r`, `ez_r`)
-    auto update_b = [&](P* bb, const P* e, const P* e_kp, const P& ex_jp, const P& ez_jp, T ey_r, T ez_r,
-                        int kp, int km, int step, int mpar, bool st, const P& pre_y, const P& pre_z) {
-        int lkh;
-        const int zkh = zone_h(km, Nz, a.np[2][0], a.np[2][1], true, lkh);
-        const bool bl_lt = km >= 0 && km < Nz, bl_in = km >= 1 && km < Nz;
-        const int kpc = kp < 0 ? 0 : (kp < a.nzp ? kp : a.nzp - 1);
-        auto terms = [&](auto fast) {
-            if (row_lt && bl_lt) {
-                uterm(fast, Plus{}, bb[0], diff<T, V>(e_kp[1], e[1]), first, zkh, lkh, 2, 3, cz, step, ap->phM[0][2], ap->phMn[0][2], kpc, 6, mpar, st);
-                uterm(fast, Minus{}, bb[0], diff<T, V>(ez_jp, e[2]), first, zyh, lyh, 1, 3, cy, step, ap->phM[0][1], ap->phMn[0][1], kpc, 7, mpar, st);
-            }
-            if (bl_lt && row_in) {
-                xterm(fast, Plus{}, bb[1], diff_fwd_x<T, V>(e[2], ez_r), 3, xch, step, pre_y, ap->phMn[1][0], kpc, 8, mpar, st);
-                uterm(fast, Minus{}, bb[1], diff<T, V>(e_kp[0], e[0]), false, zkh, lkh, 2, 3, cz, step, ap->phM[1][2], ap->phMn[1][2], kpc, 9, mpar, st);
-            }
-            if (row_lt && bl_in) {
-                uterm(fast, Plus{}, bb[2], diff<T, V>(ex_jp, e[0]), false, zyh, lyh, 1, 3, cy, step, ap->phM[2][1], ap->phMn[2][1], kpc, 10, mpar, st);
-                xterm(fast, Minus{}, bb[2], diff_fwd_x<T, V>(e[1], ey_r), 3, xch, step, pre_z, ap->phMn[2][0], kpc, 11, mpar, st);
-            }
-        };
-        if constexpr (!PML) terms(std::true_type{});
-        else if (!wave_x && !y_layer_h && zkh != Z_NEG && zkh != Z_POS) terms(std::true_type{});
-        else terms(std::false_type{});
-    };
-
-    // H0 of the plane below the first one visited
-    P hx_km = zero_pack<T, V>(), hy_km = zero_pack<T, V>();
-    if (kb - 2 >= 0 && kb - 2 + a.zoff >= 0) {
-        const size_t r2 = ((size_t)(kb - 2) * a.ny1 + j) * px + c0;
-        P m0 = zero_pack<T, V>(), m1 = zero_pack<T, V>();
-        if (MU) { m0 = ldg<T, V>(ap->mu[0] + r2, lc); m1 = ldg<T, V>(ap->mu[1] + r2, lc); }
-        hx_km = h_of(ldg<T, V>(ap->B[0] + r2, lc), m0); hy_km = h_of(ldg<T, V>(ap->B[1] + r2, lc), m1);
+    // A workgroup none of whose cells, in any of the four stages, comes near a CPML layer runs the loop compiled
+    // without the layer code (the straight-line loop of a grid without CPML); the others the general one.
+    bool near_x = false, near_y = false, near_z = false;
+    if constexpr (PML) {
+        const int r0 = by * (W - 3) - 1;
+        near_x = (a.np[0][0] > 0 && c0 < a.xwn) || (a.np[0][1] > 0 && c0 + TW > a.xp0);
+        near_y = (a.np[1][0] > 0 && r0 <= a.np[1][0]) || (a.np[1][1] > 0 && r0 + W - 1 >= Ny - a.np[1][1]);
+        const int g_lo = kb - 4 + a.zoff + 1, g_hi = ke + 1 + a.zoff;      // global planes the stages of this chunk touch
+        near_z = (a.np[2][0] > 0 && g_lo <= a.np[2][0]) || (a.np[2][1] > 0 && g_hi >= Nz - a.np[2][1]);
     }
-    P b0_km[3], mu_km[3], e1_km[3], d1_km[3], ep_km[3];        // step-n state of plane k-1
-    P h1_km2[2], b1_km2[3], e2_km2[3];                         // step-n+1 inputs of plane k-2
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        b0_km[c] = mu_km[c] = e1_km[c] = d1_km[c] = ep_km[c] = b1_km2[c] = e2_km2[c] = zero_pack<T, V>();
-    }
-    h1_km2[0] = h1_km2[1] = zero_pack<T, V>();
+    // One loop per combination of layer families a workgroup can meet (x strips, y layers, z layers): each only carries
+    // the code and the scalar state of its own families.
+    auto run = [&](auto lx_tag, auto ly_tag, auto lz_tag) {
+        constexpr bool LX = PML && decltype(lx_tag)::value, LY = PML && decltype(ly_tag)::value, LZ = PML && decltype(lz_tag)::value;
+        constexpr bool LAYERS = LX || LY || LZ;
+        int lye, lyh;
+        const int zye = zone_e(j, Ny, a.np[1][0], a.np[1][1], lye);
+        const int zyh = zone_h(j, Ny, a.np[1][0], a.np[1][1], true, lyh);
+        const bool in_n = LX && a.np[0][0] > 0 && i0 < a.xwn;
+        const bool in_p = LX && a.np[0][1] > 0 && i0 >= a.xp0 && i0 < a.xp0 + a.xwp;
+        const bool wave_x = LX && __ballot(in_n || in_p) != 0;                       // some lane of this wave lies in an x strip
+        const bool y_layer_e = LY && (zye == Z_NEG || zye == Z_POS), y_layer_h = LY && (zyh == Z_NEG || zyh == Z_POS);
 
-    for (int kl = kb - 1; kl <= ke + 1; ++kl) {
-        asm volatile("" : "+s"(ap));
-        const int klc = kl < a.nzp ? kl : a.nzp - 1;          // iterations past the last plane only drain the pipeline
-        const size_t ro = ((size_t)klc * a.ny1 + j) * px + c0;
-        const int k = kl + a.zoff;
-        const int par = kl & 1;
-
-        // ------------------------------------------------------------ A: D1(k), E1(k)
-        P bo[3], mu_[3], d1[3], ep[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) bo[c] = ldg<T, V>(ap->B[c] + ro, lc);
-        if (MU) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) mu_[c] = ldg<T, V>(ap->mu[c] + ro, lc);
-        } else {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) mu_[c] = zero_pack<T, V>();
-        }
-        const size_t rj = j >= 1 ? ro - px : ro;
-        const P b0j = ldg<T, V>(ap->B[0] + rj, lc), b2j = ldg<T, V>(ap->B[2] + rj, lc);
-        P m0j = zero_pack<T, V>(), m2j = zero_pack<T, V>();
-        if (MU) { m0j = ldg<T, V>(ap->mu[0] + rj, lc); m2j = ldg<T, V>(ap->mu[2] + rj, lc); }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { d1[c] = ldg<T, V>(ap->D[c] + ro, lc); ep[c] = ldg<T, V>(ap->eps[c] + ro, lc); }
-        // lanes inside an x strip: the old CPML state of this iteration's first-step terms
-        const P xe_y = x_request(0, ap->phE[1][0], klc, 3, par), xe_z = x_request(0, ap->phE[2][0], klc, 4, par);
-        const int klm = kl >= 1 ? (kl - 1 < a.nzp ? kl - 1 : a.nzp - 1) : 0;
-        P xm_y = zero_pack<T, V>(), xm_z = zero_pack<T, V>();
-        if (kl >= kb) { xm_y = x_request(0, ap->phM[1][0], klm, 8, par ^ 1); xm_z = x_request(0, ap->phM[2][0], klm, 11, par ^ 1); }
-
-        const P hx = h_of(bo[0], mu_[0]), hy = h_of(bo[1], mu_[1]), hz = h_of(bo[2], mu_[2]);
-        P hx_jm = zero_pack<T, V>(), hz_jm = zero_pack<T, V>();
-        if (j >= 1) { hx_jm = h_of(b0j, m0j); hz_jm = h_of(b2j, m2j); }
-        {
-            const T hy_l = left_of_tile(__shfl_up(hy.v[V - 1], 1)), hz_l = left_of_tile(__shfl_up(hz.v[V - 1], 1));
-            update_d(d1, hx, hy, hz, hx_km, hy_km, hx_jm, hz_jm, hy_l, hz_l, kl, k, 0, par, false, xe_y, xe_z);
-        }
-        P e1[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) e1[c] = divide<T, V>(d1[c], ep[c]);
-        lds_st<T, V>(slot(e1s, par, w), e1[0]); lds_st<T, V>(slot(e1s, par, w) + TW, e1[2]);
-
-        // ------------------------------------------------------------ B: B1(k-1), H1(k-1)
-        P b1[3], h1[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { b1[c] = b0_km[c]; h1[c] = zero_pack<T, V>(); }
-        if (kl >= kb) {
-            const T* up = slot(e1s, par ^ 1, w_up);              // E1(k-1) of the row above, published one iteration ago
-            const P ex_jp = lds_ld<T, V>(up), ez_jp = lds_ld<T, V>(up + TW);
-            const T ey_r = right_of_tile(__shfl_down(e1_km[1].v[0], 1)), ez_r = right_of_tile(__shfl_down(e1_km[2].v[0], 1));
-            update_b(b1, e1_km, e1, ex_jp, ez_jp, ey_r, ez_r, kl - 1, k - 1, 0, par ^ 1, false, xm_y, xm_z);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) h1[c] = h_of(b1[c], mu_km[c]);
-            lds_st<T, V>(slot(h1s, par, w), h1[0]); lds_st<T, V>(slot(h1s, par, w) + TW, h1[2]);
-        }
+        // LDS: [6][TW] x coefficients (b, a, C of the D side, then of the B side); then three regions
+        // [2 planes][W rows][2 comps][TW]: E1 (x, z) for the row below, H1 (x, z) for the row above, E2 (x, z) for the row below
+        T* const xs = smem;
+        const size_t region = (size_t)2 * W * 2 * TW;
+        T* const e1s = smem + 6 * TW;
+        T* const h1s = e1s + region;
+        T* const e2s = h1s + region;
+        for (int q = w; q < 6; q += W) lds_st<T, V>(xs + (size_t)q * TW + lo, ldg<T, V>(a.xrow + (size_t)q * px + c0, lc));
         __syncthreads();
+        const P xcd = lds_ld<T, V>(xs + 2 * TW + lo), xch = lds_ld<T, V>(xs + 5 * TW + lo);
+        auto slot = [&](T* reg, int par, int row) -> T* { return reg + ((size_t)(par * W + row) * 2) * TW + lo; };
+        const int w_up = w + 1 < W ? w + 1 : w, w_dn = w >= 1 ? w - 1 : w;
+        // CPML state between the two steps of a cell: 12 terms x 2 planes in flight, private to the wave, in device memory
+        // (only touched inside the layers; the second step reads it back one iteration later, from L2)
+        // (what only the layers need -- array extents, table and scratch pointers -- is read from the argument block
+        // where it is used, not kept in scalar registers through the loop)
+        const unsigned mid_off = (unsigned)(((size_t)blockIdx.x * W + w) * 24 * TW);
+        auto mid_of = [&](int mpar, int term) -> T* { return ap->pair_scr + mid_off + (size_t)(mpar * 12 + term) * TW; };
 
-        // ------------------------------------------------------------ C: D2(k-1), E2(k-1)
-        P e2[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) e2[c] = zero_pack<T, V>();
-        // lanes inside an x strip: the state their second-step terms left behind one iteration ago
-        P x2e_y = zero_pack<T, V>(), x2e_z = zero_pack<T, V>(), x2m_y = zero_pack<T, V>(), x2m_z = zero_pack<T, V>();
-        if (kl >= kb + 1) { x2e_y = x_request(1, ap->phE[1][0], 0, 3, par ^ 1); x2e_z = x_request(1, ap->phE[2][0], 0, 4, par ^ 1); }
-        if (kl >= kb + 2) { x2m_y = x_request(1, ap->phM[1][0], 0, 8, par); x2m_z = x_request(1, ap->phM[2][0], 0, 11, par); }
-        if (kl >= kb + 1) {
-            asm volatile("" : "+s"(ap));
-            const T* dn = slot(h1s, par, w_dn);                  // H1(k-1) of the row below, published before the barrier
-            P hx_jm1 = lds_ld<T, V>(dn), hz_jm1 = lds_ld<T, V>(dn + TW);
-            if (j < 1) { hx_jm1 = zero_pack<T, V>(); hz_jm1 = zero_pack<T, V>(); }
-            const T hy_l = left_of_tile(__shfl_up(h1[1].v[V - 1], 1)), hz_l = left_of_tile(__shfl_up(h1[2].v[V - 1], 1));
-            const int km = k - 1;
-            const bool st = own && kl - 1 < ke;
-            P d2[3] = {d1_km[0], d1_km[1], d1_km[2]};
-            update_d(d2, h1[0], h1[1], h1[2], h1_km2[0], h1_km2[1], hx_jm1, hz_jm1, hy_l, hz_l, kl - 1, km, 1, par ^ 1, st, x2e_y, x2e_z);
-            if (st) {
-                const size_t rs = ro - sz * (size_t)(klc - (kl - 1));
-                stg_nt<T, V>(ap->Dn[0] + rs, lo, d2[0]);
-                if (row_lt) stg_nt<T, V>(ap->Dn[1] + rs, lo, d2[1]);
-                if (km >= 0 && km < Nz) stg_nt<T, V>(ap->Dn[2] + rs, lo, d2[2]);
+        auto h_of = [&](const P& b, const P& m) -> P { return MU ? divide<T, V>(b, m) : divide<T, V>(b, a.mu0); };
+        auto left_of_tile = [&](T shifted) -> T { return (lane == 0 && bx == 0) ? (T)0 : shifted; };
+        auto right_of_tile = [&](T shifted) -> T { return wall_r ? (T)0 : shifted; };
+
+        // ---- the two kinds of term.  step 0: state from the old buffers into `mid`; step 1: from `mid` into the new buffers.
+        // Offsets into the CPML arrays are only formed inside the layers (most waves never get there).
+        // zone-uniform axis (1 = y, 2 = z); kpc = local plane of the cell (y-face arrays are [plane][layer][column])
+        auto uterm = [&](auto fast, auto sign, P& d, const P& curl, bool skip0, int zone, int l, auto axis_tag, int kb3, T cmid,
+                         int step, Slots<T> src, Slots<T> dst, int kpc, int term, int mpar, bool st, bool have_pre, const P& pre) {
+            constexpr int SIGN = decltype(sign)::value;
+            constexpr bool FAST = decltype(fast)::value;          // the caller knows that no term of this stage lies in a layer
+            constexpr int axis = decltype(axis_tag)::value;
+            constexpr bool ON = axis == 2 ? LZ : LY;              // this workgroup can meet layers of this axis at all
+            if (zone == Z_NONE) return;
+            if (FAST || !ON || zone == Z_MID) { pair_axpy<SIGN, T, V>(d, cmid, curl, skip0); return; }
+            if constexpr (ON && !FAST) {
+                const int side = zone == Z_POS;
+                const size_t off = axis == 2 ? ((size_t)l * ap->ny1 + j) * px + c0 : ((size_t)kpc * ap->np[1][side] + l) * px + c0;
+                const T* face = ap->tab + (size_t)(axis * 2) * 6 * kMaxLayers;
+                T* const m = mid_of(mpar, term);
+                P ph = pre;
+                if (!have_pre) ph = step == 0 ? ldg<T, V>(src[side] + off, lc) : ldg<T, V>(m, lo);
+                pair_cpml_u<SIGN, T, V>(d, curl, skip0, side != 0, face + kb3 * kMaxLayers + l, dt, ph);
+                if (step == 0) stg<T, V>(m, lo, ph);
+                else if (st) stg<T, V>(dst[side] + off, lo, ph);
             }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) e2[c] = divide<T, V>(d2[c], ep_km[c]);
-            lds_st<T, V>(slot(e2s, par, w), e2[0]); lds_st<T, V>(slot(e2s, par, w) + TW, e2[2]);
-        }
-
-        // ------------------------------------------------------------ D: B2(k-2)
-        if (kl >= kb + 2) {
-            const T* up = slot(e2s, par ^ 1, w_up);              // E2(k-2) of the row above, published one iteration ago
-            const P ex_jp = lds_ld<T, V>(up), ez_jp = lds_ld<T, V>(up + TW);
-            const T ey_r = right_of_tile(__shfl_down(e2_km2[1].v[0], 1)), ez_r = right_of_tile(__shfl_down(e2_km2[2].v[0], 1));
-            const int km2 = k - 2;
-            const bool bl_lt = km2 >= 0 && km2 < Nz;
-            P b2[3] = {b1_km2[0], b1_km2[1], b1_km2[2]};
-            update_b(b2, e2_km2, e2, ex_jp, ez_jp, ey_r, ez_r, kl - 2, km2, 1, par, own, x2m_y, x2m_z);
-            if (own) {
-                const size_t rs = ro - sz * (size_t)(klc - (kl - 2));
-                if (row_lt && bl_lt) stg_nt<T, V>(ap->Bn[0] + rs, lo, b2[0]);
-                if (bl_lt) stg_nt<T, V>(ap->Bn[1] + rs, lo, b2[1]);
-                if (row_lt) stg_nt<T, V>(ap->Bn[2] + rs, lo, b2[2]);
+        };
+        // A wave waits for memory once per stage, not once per term: the state of ONE family of layers -- the x strips if
+        // the wave has lanes in them, else the y layers if its row lies in one, else the z layers if the plane does -- is
+        // requested ahead of the stage (with the field loads in step 0, right after the barrier in step 1); the terms of
+        // another family that applies as well (edges and corners of the box) fetch theirs where they need it.
+        auto family = [&](bool ylayer, int zk) -> int {
+            return __builtin_amdgcn_readfirstlane((LX && wave_x) ? 1 : ((LY && ylayer) ? 2 : ((LZ && (zk == Z_NEG || zk == Z_POS)) ? 3 : 0)));
+        };
+        // the idx-th (0, 1) term of family `fam` on the D side (mag = false) or the B side: state of step 0 from the old
+        // buffers (plane kpc; z layer lk of zone zk), of step 1 from `mid`
+        auto request = [&](int fam, bool mag, int idx, int step, int kpc, int zk, int lk, int mpar) -> P {
+            P ph = zero_pack<T, V>();
+            if constexpr (LAYERS) {
+                if (fam == 0) return ph;
+                const int axis = fam == 1 ? 0 : (fam == 2 ? 1 : 2);
+                int comp, term;
+                if (fam == 1) { comp = idx ? 2 : 1; term = mag ? (idx ? 11 : 8) : (idx ? 4 : 3); }
+                else if (fam == 2) { comp = idx ? 2 : 0; term = mag ? (idx ? 10 : 7) : (idx ? 5 : 1); }
+                else { comp = idx ? 1 : 0; term = mag ? (idx ? 9 : 6) : (idx ? 2 : 0); }
+                if (step == 1) {
+                    // (a plain per-lane address: with the term number only known at run time the compiler does not accept
+                    // this base as wave-uniform)
+                    const T* const m = mid_of(mpar, term) + lo;
+                    if (fam != 1) ph = lds_ld<T, V>(m);
+                    else if (in_n || in_p) ph = lds_ld<T, V>(m);
+                    return ph;
+                }
+                Slots<T> src = mag ? (Slots<T>)ap->phM[comp][axis] : (Slots<T>)ap->phE[comp][axis];
+                if (LX && fam == 1) {
+                    const size_t row = (size_t)kpc * ap->ny1 + j;
+                    const T* const pn = src[0] + row * ap->xwn + c0;
+                    const T* const pp = src[1] + (ptrdiff_t)(row * ap->xwp) + (c0 - ap->xp0);
+                    if (in_n) ph = ldg<T, V>(pn, lc);
+                    if (in_p) ph = ldg<T, V>(pp, lc);
+                } else if (LY && fam == 2) {
+                    const int side = (mag ? zyh : zye) == Z_POS, l = mag ? lyh : lye;
+                    ph = ldg<T, V>(src[side] + ((size_t)kpc * ap->np[1][side] + l) * px + c0, lc);
+                } else if (LZ && fam == 3) {
+                    const int side = zk == Z_POS;
+                    ph = ldg<T, V>(src[side] + ((size_t)lk * ap->ny1 + j) * px + c0, lc);
+                }
             }
-        }
+            return ph;
+        };
+        auto xterm = [&](auto fast, auto sign, P& d, const P& curl, int kb3, const P& xc, int step, P ph, Slots<T> dst, int kpc, int term, int mpar, bool st) {
+            constexpr int SIGN = decltype(sign)::value;
+            constexpr bool FAST = decltype(fast)::value;
+            if (LX && !FAST && (in_n || in_p)) {
+                if constexpr (LX && !FAST) {
+                    const P b = lds_ld<T, V>(xs + (size_t)kb3 * TW + lo), aa = lds_ld<T, V>(xs + (size_t)(kb3 + 1) * TW + lo);
+                    pair_cpml_x<SIGN, T, V>(d, curl, b, aa, xc, dt, ph);
+                    if (step == 0) stg<T, V>(mid_of(mpar, term), lo, ph);
+                    else if (st) {
+                        const size_t row = (size_t)kpc * ap->ny1 + j;
+                        if (in_n) stg<T, V>(dst[0] + row * ap->xwn + c0, lc, ph); else stg<T, V>(dst[1] + (ptrdiff_t)(row * ap->xwp) + (c0 - ap->xp0), lc, ph);
+                    }
+                }
+            } else {
+                pair_axpy_x<SIGN, T, V>(d, xc, curl);
+            }
+        };
+        using AxY = std::integral_constant<int, 1>;
+        using AxZ = std::integral_constant<int, 2>;
+        using Plus = std::integral_constant<int, +1>;
+        using Minus = std::integral_constant<int, -1>;
 
-        // ------------------------------------------------------------ hand-over to the next iteration
-        hx_km = hx; hy_km = hy;
-        h1_km2[0] = h1[0]; h1_km2[1] = h1[1];
+        // D of plane (kp local, k global) from H of the same step: terms, order and index ranges of k3_fused
+        auto update_d = [&](P* dd, const P& hx, const P& hy, const P& hz, const P& hx_m, const P& hy_m, const P& hx_jm, const P& hz_jm,
+                            T hy_l, T hz_l, int kp, int k, int step, int mpar, bool st, int fam, const P& pre0, const P& pre1) {
+            int lke;
+            const int zke = zone_e(k, Nz, a.np[2][0], a.np[2][1], lke);
+            const bool pl_lt = k >= 0 && k < Nz, pl_in = k >= 1 && k < Nz;
+            const int kpc = kp < a.nzp ? kp : a.nzp - 1;
+            auto terms = [&](auto fast) {
+                if (row_lt) uterm(fast, Minus{}, dd[0], diff<T, V>(hy, hy_m), false, zke, lke, AxZ{}, 0, cz, step, ap->phE[0][2], ap->phEn[0][2], kpc, 0, mpar, st, fam == 3, pre0);
+                if (pl_in) uterm(fast, Plus{}, dd[0], diff<T, V>(hz, hz_jm), false, zye, lye, AxY{}, 0, cy, step, ap->phE[0][1], ap->phEn[0][1], kpc, 1, mpar, st, fam == 2, pre0);
+                if (((a.src_on >> step) & 1) && k == a.kJ) {
+                    const P m = ldg<T, V>(a.mag + (size_t)j * px + c0, lc);
+                    const T jx = step == 0 ? a.jx : a.jx2;
+#pragma unroll
+                    for (int e = 0; e < V; ++e) dd[0].v[e] = dd[0].v[e] + jx * m.v[e];
+                }
+                if (row_lt) {
+                    uterm(fast, Plus{}, dd[1], diff<T, V>(hx, hx_m), first, zke, lke, AxZ{}, 0, cz, step, ap->phE[1][2], ap->phEn[1][2], kpc, 2, mpar, st, fam == 3, pre1);
+                    if (pl_in) xterm(fast, Minus{}, dd[1], diff_back_x<T, V>(hz, hz_l), 0, xcd, step, pre0, ap->phEn[1][0], kpc, 3, mpar, st);
+                }
+                if (pl_lt) {
+                    if (row_in) xterm(fast, Plus{}, dd[2], diff_back_x<T, V>(hy, hy_l), 0, xcd, step, pre1, ap->phEn[2][0], kpc, 4, mpar, st);
+                    uterm(fast, Minus{}, dd[2], diff<T, V>(hx, hx_jm), first, zye, lye, AxY{}, 0, cy, step, ap->phE[2][1], ap->phEn[2][1], kpc, 5, mpar, st, fam == 2, pre1);
+                }
+            };
+            // most waves are nowhere near a layer: they take the straight-line code of the kernel without CPML
+            if constexpr (!LAYERS) terms(std::true_type{});
+            else if (!wave_x && !y_layer_e && (!LZ || (zke != Z_NEG && zke != Z_POS))) terms(std::true_type{});
+            else terms(std::false_type{});
+        };
+        // B of plane (kp local, km global) from E of the same step at planes km (`e`) and km+1 (`e_kp`), the row above
+        // (`ex_jp`, `ez_jp`) and the column to the right (`ey_r`, `ez_r`)
+        auto update_b = [&](P* bb, const P* e, const P* e_kp, const P& ex_jp, const P& ez_jp, T ey_r, T ez_r,
+                            int kp, int km, int step, int mpar, bool st, int fam, const P& pre0, const P& pre1) {
+            int lkh;
+            const int zkh = zone_h(km, Nz, a.np[2][0], a.np[2][1], true, lkh);
+            const bool bl_lt = km >= 0 && km < Nz, bl_in = km >= 1 && km < Nz;
+            const int kpc = kp < 0 ? 0 : (kp < a.nzp ? kp : a.nzp - 1);
+            auto terms = [&](auto fast) {
+                if (row_lt && bl_lt) {
+                    uterm(fast, Plus{}, bb[0], diff<T, V>(e_kp[1], e[1]), first, zkh, lkh, AxZ{}, 3, cz, step, ap->phM[0][2], ap->phMn[0][2], kpc, 6, mpar, st, fam == 3, pre0);
+                    uterm(fast, Minus{}, bb[0], diff<T, V>(ez_jp, e[2]), first, zyh, lyh, AxY{}, 3, cy, step, ap->phM[0][1], ap->phMn[0][1], kpc, 7, mpar, st, fam == 2, pre0);
+                }
+                if (bl_lt && row_in) {
+                    xterm(fast, Plus{}, bb[1], diff_fwd_x<T, V>(e[2], ez_r), 3, xch, step, pre0, ap->phMn[1][0], kpc, 8, mpar, st);
+                    uterm(fast, Minus{}, bb[1], diff<T, V>(e_kp[0], e[0]), false, zkh, lkh, AxZ{}, 3, cz, step, ap->phM[1][2], ap->phMn[1][2], kpc, 9, mpar, st, fam == 3, pre1);
+                }
+                if (row_lt && bl_in) {
+                    uterm(fast, Plus{}, bb[2], diff<T, V>(ex_jp, e[0]), false, zyh, lyh, AxY{}, 3, cy, step, ap->phM[2][1], ap->phMn[2][1], kpc, 10, mpar, st, fam == 2, pre1);
+                    xterm(fast, Minus{}, bb[2], diff_fwd_x<T, V>(e[1], ey_r), 3, xch, step, pre1, ap->phMn[2][0], kpc, 11, mpar, st);
+                }
+            };
+            if constexpr (!LAYERS) terms(std::true_type{});
+            else if (!wave_x && !y_layer_h && (!LZ || (zkh != Z_NEG && zkh != Z_POS))) terms(std::true_type{});
+            else terms(std::false_type{});
+        };
+
+        // H0 of the plane below the first one visited
+        P hx_km = zero_pack<T, V>(), hy_km = zero_pack<T, V>();
+        if (kb - 2 >= 0 && kb - 2 + a.zoff >= 0) {
+            const size_t r2 = ((size_t)(kb - 2) * a.ny1 + j) * px + c0;
+            P m0 = zero_pack<T, V>(), m1 = zero_pack<T, V>();
+            if (MU) { m0 = ldg<T, V>(ap->mu[0] + r2, lc); m1 = ldg<T, V>(ap->mu[1] + r2, lc); }
+            hx_km = h_of(ldg<T, V>(ap->B[0] + r2, lc), m0); hy_km = h_of(ldg<T, V>(ap->B[1] + r2, lc), m1);
+        }
+        P b0_km[3], mu_km[3], e1_km[3], d1_km[3], ep_km[3];        // step-n state of plane k-1
+        P h1_km2[2], b1_km2[3], e2_km2[3];                         // step-n+1 inputs of plane k-2
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            b0_km[c] = bo[c]; mu_km[c] = mu_[c]; e1_km[c] = e1[c]; d1_km[c] = d1[c]; ep_km[c] = ep[c];
-            b1_km2[c] = b1[c]; e2_km2[c] = e2[c];
+            b0_km[c] = mu_km[c] = e1_km[c] = d1_km[c] = ep_km[c] = b1_km2[c] = e2_km2[c] = zero_pack<T, V>();
         }
+        h1_km2[0] = h1_km2[1] = zero_pack<T, V>();
+
+        for (int kl = kb - 1; kl <= ke + 1; ++kl) {
+            asm volatile("" : "+s"(ap));
+            const int klc = kl < a.nzp ? kl : a.nzp - 1;          // iterations past the last plane only drain the pipeline
+            const size_t ro = ((size_t)klc * a.ny1 + j) * px + c0;
+            const int k = kl + a.zoff;
+            const int par = kl & 1;
+
+            // ------------------------------------------------------------ A: D1(k), E1(k)
+            P bo[3], mu_[3], d1[3], ep[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) bo[c] = ldg<T, V>(ap->B[c] + ro, lc);
+            if (MU) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) mu_[c] = ldg<T, V>(ap->mu[c] + ro, lc);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) mu_[c] = zero_pack<T, V>();
+            }
+            const size_t rj = j >= 1 ? ro - px : ro;
+            const P b0j = ldg<T, V>(ap->B[0] + rj, lc), b2j = ldg<T, V>(ap->B[2] + rj, lc);
+            P m0j = zero_pack<T, V>(), m2j = zero_pack<T, V>();
+            if (MU) { m0j = ldg<T, V>(ap->mu[0] + rj, lc); m2j = ldg<T, V>(ap->mu[2] + rj, lc); }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { d1[c] = ldg<T, V>(ap->D[c] + ro, lc); ep[c] = ldg<T, V>(ap->eps[c] + ro, lc); }
+            // the CPML state this iteration's first-step terms start from (one family of layers per stage, see `family`)
+            int lkA, lkB;
+            const int zkA = zone_e(k, Nz, a.np[2][0], a.np[2][1], lkA), zkB = zone_h(k - 1, Nz, a.np[2][0], a.np[2][1], true, lkB);
+            const int famA = LAYERS ? family(y_layer_e, zkA) : 0, famB = (LAYERS && kl >= kb) ? family(y_layer_h, zkB) : 0;
+            const int klm = kl >= 1 ? (kl - 1 < a.nzp ? kl - 1 : a.nzp - 1) : 0;
+            const P preA0 = request(famA, false, 0, 0, klc, zkA, lkA, par), preA1 = request(famA, false, 1, 0, klc, zkA, lkA, par);
+            const P preB0 = request(famB, true, 0, 0, klm, zkB, lkB, par ^ 1), preB1 = request(famB, true, 1, 0, klm, zkB, lkB, par ^ 1);
+
+            const P hx = h_of(bo[0], mu_[0]), hy = h_of(bo[1], mu_[1]), hz = h_of(bo[2], mu_[2]);
+            P hx_jm = zero_pack<T, V>(), hz_jm = zero_pack<T, V>();
+            if (j >= 1) { hx_jm = h_of(b0j, m0j); hz_jm = h_of(b2j, m2j); }
+            {
+                const T hy_l = left_of_tile(__shfl_up(hy.v[V - 1], 1)), hz_l = left_of_tile(__shfl_up(hz.v[V - 1], 1));
+                update_d(d1, hx, hy, hz, hx_km, hy_km, hx_jm, hz_jm, hy_l, hz_l, kl, k, 0, par, false, famA, preA0, preA1);
+            }
+            P e1[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) e1[c] = divide<T, V>(d1[c], ep[c]);
+            lds_st<T, V>(slot(e1s, par, w), e1[0]); lds_st<T, V>(slot(e1s, par, w) + TW, e1[2]);
+
+            // ------------------------------------------------------------ B: B1(k-1), H1(k-1)
+            P b1[3], h1[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { b1[c] = b0_km[c]; h1[c] = zero_pack<T, V>(); }
+            if (kl >= kb) {
+                const T* up = slot(e1s, par ^ 1, w_up);              // E1(k-1) of the row above, published one iteration ago
+                const P ex_jp = lds_ld<T, V>(up), ez_jp = lds_ld<T, V>(up + TW);
+                const T ey_r = right_of_tile(__shfl_down(e1_km[1].v[0], 1)), ez_r = right_of_tile(__shfl_down(e1_km[2].v[0], 1));
+                update_b(b1, e1_km, e1, ex_jp, ez_jp, ey_r, ez_r, kl - 1, k - 1, 0, par ^ 1, false, famB, preB0, preB1);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) h1[c] = h_of(b1[c], mu_km[c]);
+                lds_st<T, V>(slot(h1s, par, w), h1[0]); lds_st<T, V>(slot(h1s, par, w) + TW, h1[2]);
+            }
+            __syncthreads();
+
+            // ------------------------------------------------------------ C: D2(k-1), E2(k-1)
+            P e2[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) e2[c] = zero_pack<T, V>();
+            // the state the second-step terms of this iteration continue from (left in `mid` one iteration ago)
+            int lkC, lkD;
+            const int zkC = zone_e(k - 1, Nz, a.np[2][0], a.np[2][1], lkC), zkD = zone_h(k - 2, Nz, a.np[2][0], a.np[2][1], true, lkD);
+            const int famC = (LAYERS && kl >= kb + 1) ? family(y_layer_e, zkC) : 0, famD = (LAYERS && kl >= kb + 2) ? family(y_layer_h, zkD) : 0;
+            const P preC0 = request(famC, false, 0, 1, 0, zkC, lkC, par ^ 1), preC1 = request(famC, false, 1, 1, 0, zkC, lkC, par ^ 1);
+            const P preD0 = request(famD, true, 0, 1, 0, zkD, lkD, par), preD1 = request(famD, true, 1, 1, 0, zkD, lkD, par);
+            if (kl >= kb + 1) {
+                asm volatile("" : "+s"(ap));
+                const T* dn = slot(h1s, par, w_dn);                  // H1(k-1) of the row below, published before the barrier
+                P hx_jm1 = lds_ld<T, V>(dn), hz_jm1 = lds_ld<T, V>(dn + TW);
+                if (j < 1) { hx_jm1 = zero_pack<T, V>(); hz_jm1 = zero_pack<T, V>(); }
+                const T hy_l = left_of_tile(__shfl_up(h1[1].v[V - 1], 1)), hz_l = left_of_tile(__shfl_up(h1[2].v[V - 1], 1));
+                const int km = k - 1;
+                const bool st = own && kl - 1 < ke;
+                P d2[3] = {d1_km[0], d1_km[1], d1_km[2]};
+                update_d(d2, h1[0], h1[1], h1[2], h1_km2[0], h1_km2[1], hx_jm1, hz_jm1, hy_l, hz_l, kl - 1, km, 1, par ^ 1, st, famC, preC0, preC1);
+                if (st) {
+                    const size_t rs = ro - sz * (size_t)(klc - (kl - 1));
+                    stg_nt<T, V>(ap->Dn[0] + rs, lo, d2[0]);
+                    if (row_lt) stg_nt<T, V>(ap->Dn[1] + rs, lo, d2[1]);
+                    if (km >= 0 && km < Nz) stg_nt<T, V>(ap->Dn[2] + rs, lo, d2[2]);
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) e2[c] = divide<T, V>(d2[c], ep_km[c]);
+                lds_st<T, V>(slot(e2s, par, w), e2[0]); lds_st<T, V>(slot(e2s, par, w) + TW, e2[2]);
+            }
+
+            // ------------------------------------------------------------ D: B2(k-2)
+            if (kl >= kb + 2) {
+                const T* up = slot(e2s, par ^ 1, w_up);              // E2(k-2) of the row above, published one iteration ago
+                const P ex_jp = lds_ld<T, V>(up), ez_jp = lds_ld<T, V>(up + TW);
+                const T ey_r = right_of_tile(__shfl_down(e2_km2[1].v[0], 1)), ez_r = right_of_tile(__shfl_down(e2_km2[2].v[0], 1));
+                const int km2 = k - 2;
+                const bool bl_lt = km2 >= 0 && km2 < Nz;
+                P b2[3] = {b1_km2[0], b1_km2[1], b1_km2[2]};
+                update_b(b2, e2_km2, e2, ex_jp, ez_jp, ey_r, ez_r, kl - 2, km2, 1, par, own, famD, preD0, preD1);
+                if (own) {
+                    const size_t rs = ro - sz * (size_t)(klc - (kl - 2));
+                    if (row_lt && bl_lt) stg_nt<T, V>(ap->Bn[0] + rs, lo, b2[0]);
+                    if (bl_lt) stg_nt<T, V>(ap->Bn[1] + rs, lo, b2[1]);
+                    if (row_lt) stg_nt<T, V>(ap->Bn[2] + rs, lo, b2[2]);
+                }
+            }
+
+            // ------------------------------------------------------------ hand-over to the next iteration
+            hx_km = hx; hy_km = hy;
+            h1_km2[0] = h1[0]; h1_km2[1] = h1[1];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                b0_km[c] = bo[c]; mu_km[c] = mu_[c]; e1_km[c] = e1[c]; d1_km[c] = d1[c]; ep_km[c] = ep[c];
+                b1_km2[c] = b1[c]; e2_km2[c] = e2[c];
+            }
+        }
+    };
+    using No = std::false_type;
+    using Yes = std::true_type;
+    if constexpr (!PML) run(No{}, No{}, No{});
+    else if (near_x) {
+        if (near_y) { if (near_z) run(Yes{}, Yes{}, Yes{}); else run(Yes{}, Yes{}, No{}); }
+        else { if (near_z) run(Yes{}, No{}, Yes{}); else run(Yes{}, No{}, No{}); }
+    } else {
+        if (near_y) { if (near_z) run(No{}, Yes{}, Yes{}); else run(No{}, Yes{}, No{}); }
+        else { if (near_z) run(No{}, No{}, Yes{}); else run(No{}, No{}, No{}); }
     }
 }
 

@@ -11,6 +11,8 @@ from fdtd_amd import setup as fs, engine as E
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=1024)
 ap.add_argument("--nz", type=int, default=0)
+ap.add_argument("--ny", type=int, default=0)
+ap.add_argument("--nx", type=int, default=0)
 ap.add_argument("--mu", type=int, default=1)
 ap.add_argument("--prec", type=int, default=32)
 ap.add_argument("--steps", type=int, default=20)
@@ -22,7 +24,7 @@ ap.add_argument("--npml", default="0", help="layers on every face, or six number
 a = ap.parse_args()
 a.npml = tuple(int(v) for v in a.npml.split(",")) if "," in a.npml else (int(a.npml),) * 6
 K = fs.constants(); d = (1053e-9 / 20,) * 3; dt = d[0] / (K["c0"] * 2)
-N = (a.n, a.n, a.nz or a.n)
+N = (a.nx or a.n, a.ny or a.n, a.nz or a.n)
 cells = N[0] * N[1] * N[2]
 out = {"grid": list(N), "npml": list(a.npml), "precision": a.prec, "mu_grid": bool(a.mu), "steps": a.steps}
 
