@@ -1232,7 +1232,7 @@ struct Engine3 : fdtd3d_engine {
         if (chunk_pair > 0) return chunk_pair;
         const int per_layer = pair_nbx() * ((ny1 + (wpbp - 3) - 1) / (wpbp - 3));
         const int want = (1024 + per_layer - 1) / per_layer;
-        return std::max(8, std::min(96, (nzp - 1 + want - 1) / want));
+        return std::max(8, std::min(128, (nzp - 1 + want - 1) / want));
     }
     void pair_info(int out[4]) override { out[0] = pair_auto() ? 1 : 0; out[1] = pair_chunk(); out[2] = wpbp; out[3] = V / 2; }
     int step_pair(int n, hipStream_t s) override {
@@ -1241,6 +1241,8 @@ struct Engine3 : fdtd3d_engine {
         bool pml = false;
         for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) pml = pml || np[ax][sd] != 0;
         if (getenv("FDTD_PAIR_FORCE_PML")) pml = true;        // experiment: the CPML-capable kernel on a grid without layers
+        for (int m = 0; m < 2; ++m) for (int c = 0; c < 3; ++c) for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd)
+            if (phSize[m][c][ax][sd] >= ((size_t)1 << 31)) return fail(FDTD_ERR_STATE, "two-step launches index the CPML state with 32 bits: an array of %zu elements is too large", phSize[m][c][ax][sd]);
         if (phase != 0) return fail(FDTD_ERR_STATE, "two-step launch in the middle of a split step");
         constexpr int PV = V / 2, TW = kLanes * PV;
         K3<T> a = args();
@@ -1275,7 +1277,9 @@ struct Engine3 : fdtd3d_engine {
         }
         a.znb[0] = nb[0]; a.znb[1] = nb[1];
         a.nbz = nb[0] + nb[1] + nb[2];
-        a.remap = remap == kRemapAuto ? std::max(2, a.nbx) : remap;
+        // tile order: as dealt (x tiles fastest, round-robin over the XCDs) -- measured at 1024^3 with CPML: 12.3 ms
+        // against 12.7 with the x tiles of a row group kept on one XCD
+        a.remap = remap == kRemapAuto ? 0 : remap;
         const unsigned nblk = (unsigned)a.nbx * a.nby * a.nbz;
         const size_t lds = ((size_t)6 + (size_t)3 * 2 * wpbp * 2) * TW * sizeof(T);
         const size_t scr_need = pml ? (size_t)nblk * wpbp * 24 * TW : 0;

@@ -157,6 +157,10 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
         const bool in_n = LX && a.np[0][0] > 0 && i0 < a.xwn;
         const bool in_p = LX && a.np[0][1] > 0 && i0 >= a.xp0 && i0 < a.xp0 + a.xwp;
         const bool wave_x = LX && __ballot(in_n || in_p) != 0;                       // some lane of this wave lies in an x strip
+        // element offsets into the strip arrays: this row's share is fixed, a plane adds `xs_*` (32-bit: the host refuses
+        // grids whose auxiliary arrays exceed 2^31 elements)
+        const int xs_n = LX ? a.ny1 * a.xwn : 0, xs_p = LX ? a.ny1 * a.xwp : 0;
+        const int xo_n = LX ? j * a.xwn + c0 : 0, xo_p = LX ? j * a.xwp + (c0 - a.xp0) : 0;
         const bool y_layer_e = LY && (zye == Z_NEG || zye == Z_POS), y_layer_h = LY && (zyh == Z_NEG || zyh == Z_POS);
 
         // LDS: [6][TW] x coefficients (b, a, C of the D side, then of the B side); then three regions
@@ -195,7 +199,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             if (FAST || !ON || zone == Z_MID) { pair_axpy<SIGN, T, V>(d, cmid, curl, skip0); return; }
             if constexpr (ON && !FAST) {
                 const int side = zone == Z_POS;
-                const size_t off = axis == 2 ? ((size_t)l * ap->ny1 + j) * px + c0 : ((size_t)kpc * ap->np[1][side] + l) * px + c0;
+                const int off = axis == 2 ? (l * ap->ny1 + j) * px + c0 : (kpc * ap->np[1][side] + l) * px + c0;
                 const T* face = ap->tab + (size_t)(axis * 2) * 6 * kMaxLayers;
                 T* const m = mid_of(mpar, term);
                 P ph = pre;
@@ -233,17 +237,16 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
                 }
                 Slots<T> src = mag ? (Slots<T>)ap->phM[comp][axis] : (Slots<T>)ap->phE[comp][axis];
                 if (LX && fam == 1) {
-                    const size_t row = (size_t)kpc * ap->ny1 + j;
-                    const T* const pn = src[0] + row * ap->xwn + c0;
-                    const T* const pp = src[1] + (ptrdiff_t)(row * ap->xwp) + (c0 - ap->xp0);
+                    const T* const pn = src[0] + (kpc * xs_n + xo_n);
+                    const T* const pp = src[1] + (kpc * xs_p + xo_p);
                     if (in_n) ph = ldg<T, V>(pn, lc);
                     if (in_p) ph = ldg<T, V>(pp, lc);
                 } else if (LY && fam == 2) {
                     const int side = (mag ? zyh : zye) == Z_POS, l = mag ? lyh : lye;
-                    ph = ldg<T, V>(src[side] + ((size_t)kpc * ap->np[1][side] + l) * px + c0, lc);
+                    ph = ldg<T, V>(src[side] + ((kpc * ap->np[1][side] + l) * px + c0), lc);
                 } else if (LZ && fam == 3) {
                     const int side = zk == Z_POS;
-                    ph = ldg<T, V>(src[side] + ((size_t)lk * ap->ny1 + j) * px + c0, lc);
+                    ph = ldg<T, V>(src[side] + ((lk * ap->ny1 + j) * px + c0), lc);
                 }
             }
             return ph;
@@ -257,8 +260,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
                     pair_cpml_x<SIGN, T, V>(d, curl, b, aa, xc, dt, ph);
                     if (step == 0) stg<T, V>(mid_of(mpar, term), lo, ph);
                     else if (st) {
-                        const size_t row = (size_t)kpc * ap->ny1 + j;
-                        if (in_n) stg<T, V>(dst[0] + row * ap->xwn + c0, lc, ph); else stg<T, V>(dst[1] + (ptrdiff_t)(row * ap->xwp) + (c0 - ap->xp0), lc, ph);
+                        if (in_n) stg<T, V>(dst[0] + (kpc * xs_n + xo_n), lc, ph); else stg<T, V>(dst[1] + (kpc * xs_p + xo_p), lc, ph);
                     }
                 }
             } else {

@@ -140,7 +140,7 @@ int fdtd3d_step(fdtd3d_handle h, int n0, int count, void* stream);
  * a launch).  Anything else is refused with FDTD_ERR_STATE.  fdtd3d_step uses these launches by itself
  * for as many of its steps as it can when the grid is large enough for them to pay (384^3 cells; the
  * environment variable FDTD_PAIR=0/1 overrides) and no probe is registered.
- * fdtd3d_pair_shape sets the planes per workgroup (default: chosen from the grid, at most 96) and the
+ * fdtd3d_pair_shape sets the planes per workgroup (default: chosen from the grid, at most 128) and the
  * waves per workgroup (6..16, default 16; three of them are halo rows); 0 keeps. */
 int fdtd3d_step_pairs(fdtd3d_handle h, int n0, int pairs, void* stream);
 int fdtd3d_pair_shape(fdtd3d_handle h, int chunk, int rows);

@@ -19,6 +19,7 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--chunk", type=int, default=0)
 ap.add_argument("--rows", type=int, default=0)
 ap.add_argument("--only", default="")
+ap.add_argument("--remap", type=int, default=-1)
 ap.add_argument("--check", type=int, default=1)
 ap.add_argument("--npml", default="0", help="layers on every face, or six numbers x-,x+,y-,y+,z-,z+")
 a = ap.parse_args()
@@ -52,6 +53,8 @@ for kind in ("single", "pair"):
     eng = make()
     if kind == "pair":
         eng.pair_shape(a.chunk, a.rows)
+        if a.remap >= 0:
+            eng.tune(0, a.remap, 0)
         el = timed(eng, lambda n0, pairs: eng.step_pairs(n0, pairs))
     else:
         el = timed(eng, lambda n0, pairs: eng.step(n0, 2 * pairs))
