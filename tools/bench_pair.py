@@ -50,6 +50,10 @@ sums = {}
 for kind in ("single", "pair"):
     if a.only and a.only != kind:
         continue
+    if kind == "single":
+        os.environ["FDTD_PAIR"] = "0"          # step() would otherwise go two steps per launch by itself on a large grid
+    else:
+        os.environ.pop("FDTD_PAIR", None)
     eng = make()
     if kind == "pair":
         eng.pair_shape(a.chunk, a.rows)
