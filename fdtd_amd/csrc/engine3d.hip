@@ -253,6 +253,7 @@ struct fdtd3d_engine {
     virtual int step_pair(int n, hipStream_t s) = 0;
     virtual int pair_shape(int chunk, int rows) = 0;
     virtual bool pair_auto() = 0;
+    virtual void pair_give_up() = 0;
     virtual void pair_info(int out[4]) = 0;
     virtual int parity() = 0;
     virtual int fused_top(hipStream_t s) = 0;
@@ -1215,8 +1216,11 @@ struct Engine3 : fdtd3d_engine {
     }
     // fdtd3d_step takes its steps two at a time when that is the faster way: a FUSED engine holding the whole grid,
     // and enough cells that workgroups of 16 waves x long chunks still fill the chip (FDTD_PAIR=0/1 overrides)
+    bool pair_off = false;            // a two-step launch could not get its scratch memory: fdtd3d_step stays with single steps
     bool pair_auto() override {
-        if (!fused || d.z_lo != 0 || d.z_hi != d.Nz) return false;
+        if (!fused || d.z_lo != 0 || d.z_hi != d.Nz || pair_off) return false;
+        for (int m = 0; m < 2; ++m) for (int c = 0; c < 3; ++c) for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd)
+            if (phSize[m][c][ax][sd] >= ((size_t)1 << 31)) return false;       // the kernel indexes the CPML state with 32 bits
         if (const char* e = getenv("FDTD_PAIR")) return atoi(e) != 0;
         return (size_t)d.Nx * d.Ny * d.Nz >= kPairMinCells;
     }
@@ -1234,6 +1238,7 @@ struct Engine3 : fdtd3d_engine {
         const int want = (1024 + per_layer - 1) / per_layer;
         return std::max(8, std::min(128, (nzp - 1 + want - 1) / want));
     }
+    void pair_give_up() override { pair_off = true; (void)hipGetLastError(); }      // the failed allocation's error is not the next launch's
     void pair_info(int out[4]) override { out[0] = pair_auto() ? 1 : 0; out[1] = pair_chunk(); out[2] = wpbp; out[3] = V / 2; }
     int step_pair(int n, hipStream_t s) override {
         if (!fused) return fail(FDTD_ERR_STATE, "two-step launches need an engine created with FDTD3D_MODE_FUSED");
@@ -1398,10 +1403,13 @@ int fdtd3d_step(fdtd3d_handle h, int n0, int count, void* stream) {
         if (h->d.z_lo != 0 || h->d.z_hi != h->d.Nz) return fail(FDTD_ERR_STATE, "fdtd3d_step needs the whole grid on this device; slab drivers use fdtd3d_half_e / fdtd3d_half_h or fdtd3d_fused");
         const bool pairs = h->pair_auto() && h->probe_count() == 0;      // a probe is sampled after every single step
         for (int n = n0; n < n0 + count;) {
-            if (pairs && n + 2 <= n0 + count) {
-                if (int rc = h->step_pair(n, (hipStream_t)stream)) return rc;
-                n += 2;
-                continue;
+            if (pairs && n + 2 <= n0 + count && h->pair_auto()) {
+                const int rc = h->step_pair(n, (hipStream_t)stream);
+                if (rc == FDTD_OK) { n += 2; continue; }
+                // device memory for the second B-side CPML buffers or the scratch ran out: nothing has been launched,
+                // the one-step kernel needs neither
+                if (rc != FDTD_ERR_HIP) return rc;
+                h->pair_give_up();
             }
             if (int rc = h->step(n, (hipStream_t)stream)) return rc;
             if (int rc = h->probe_record((hipStream_t)stream)) return rc;

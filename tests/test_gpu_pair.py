@@ -178,3 +178,52 @@ def test_pairs_refuse_what_they_do_not_carry():
     probed.probe_add(po.DX, 3, 3, 3)
     with pytest.raises(fdtd_amd.EngineError, match="probes"):
         probed.step_pairs(0, 1)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_pairs_equal_single_steps_random_configurations(seed):
+    """Random grids, CPML layer counts per face, mu grid or not, precision, workgroup shape and step counts: the
+    engine stepping in pairs against a second engine stepping one step per launch -- checksums and sums of squares
+    of all six stored arrays and of every CPML auxiliary array, bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    prec = int(rng.choice([32, 64]))
+    tile = 124 if prec == 32 else 60
+    N = (int(rng.choice([rng.integers(5, 40), tile - 2, tile - 1, tile, tile + 1, rng.integers(tile, 3 * tile)])),
+         int(rng.integers(4, 46)), int(rng.integers(4, 40)))
+    def layers(n):
+        lo, hi = int(rng.integers(0, 1 + min(12, (n - 2) // 2))), int(rng.integers(0, 1 + min(12, (n - 2) // 2)))
+        return (lo if rng.random() < 0.8 else 0, hi if rng.random() < 0.8 else 0)
+    npml = layers(N[0]) + layers(N[1]) + layers(N[2])
+    if npml[0] and npml[1] and (N[0] - npml[1]) // 4 * 4 < -(-(npml[0] + 1) // 4) * 4:
+        npml = (0,) + npml[1:]
+    has_mu = bool(rng.integers(0, 2))
+    rows, chunk = int(rng.integers(6, 17)), int(rng.choice([1, 2, 3, 5, 8, 48]))
+    K = po.consts()
+    d = (5e-8, 6e-8, 7e-8)
+    dt = 5e-8 / (2 * K["c0"])
+    steps = 2 * int(rng.integers(3, 9)) + 1
+    kJ = int(rng.integers(0, N[2] + 1))
+    wf, mag = po.default_source3d(N[0], N[1], steps, d, dt)
+    mag = rng.random(mag.shape)
+    engs = [fdtd_amd.Engine3D(N, npml, d, dt, K["mu0"], kJ, steps, precision=prec, mode=MODE_FUSED, has_mu=has_mu) for _ in range(2)]
+    engs[0].pair_shape(chunk, rows)
+    for eng in engs:
+        for a in range(3):
+            for s_ in range(2):
+                if npml[a * 2 + s_]:
+                    tabs = po.cpml_face(npml[a * 2 + s_], s_, d[a], d[a], dt)
+                    for k in range(6):
+                        eng.set(po.tab_id(a, s_, k), tabs[k])
+        eng.set(po.JX_WF, wf)
+        eng.set(po.JX_MAG, mag)
+        eng.fill_materials(77 + seed, K["eps0"], 4 * K["eps0"], K["mu0"], (2 if has_mu else 1) * K["mu0"])
+    first = 2 * int(rng.integers(1, steps // 2))
+    engs[0].step_pairs(0, first // 2)
+    engs[0].step(first, 1)
+    engs[0].step_pairs(first + 1, (steps - first - 1) // 2)
+    for n in range(steps):
+        engs[1].step(n, 1)
+    what = f"N={N} npml={npml} mu={has_mu} fp{prec} rows={rows} chunk={chunk} steps={steps}"
+    for id_ in [po.DX, po.DY, po.DZ, po.BX, po.BY, po.BZ] + po.ALL_PHI3D:
+        if engs[0].size(id_):
+            util.assert_equal_arrays(engs[0].get(id_), engs[1].get(id_), f"{what} array {id_}")
