@@ -151,6 +151,9 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
     auto run = [&](auto lx_tag, auto ly_tag, auto lz_tag) {
         constexpr bool LX = PML && decltype(lx_tag)::value, LY = PML && decltype(ly_tag)::value, LZ = PML && decltype(lz_tag)::value;
         constexpr bool LAYERS = LX || LY || LZ;
+        // a loop that carries exactly one family knows which one a non-zero family selector means
+        constexpr int ONLY = (LX && !LY && !LZ) ? 1 : ((LY && !LX && !LZ) ? 2 : ((LZ && !LX && !LY) ? 3 : 0));
+        auto fam_is = [](int fam, int q) -> bool { return ONLY ? (ONLY == q && fam != 0) : fam == q; };
         int lye, lyh;
         const int zye = zone_e(j, Ny, a.np[1][0], a.np[1][1], lye);
         const int zyh = zone_h(j, Ny, a.np[1][0], a.np[1][1], true, lyh);
@@ -222,6 +225,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             P ph = zero_pack<T, V>();
             if constexpr (LAYERS) {
                 if (fam == 0) return ph;
+                if (ONLY) fam = ONLY;
                 const int axis = fam == 1 ? 0 : (fam == 2 ? 1 : 2);
                 int comp, term;
                 if (fam == 1) { comp = idx ? 2 : 1; term = mag ? (idx ? 11 : 8) : (idx ? 4 : 3); }
@@ -280,8 +284,8 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             const bool pl_lt = k >= 0 && k < Nz, pl_in = k >= 1 && k < Nz;
             const int kpc = kp < a.nzp ? kp : a.nzp - 1;
             auto terms = [&](auto fast) {
-                if (row_lt) uterm(fast, Minus{}, dd[0], diff<T, V>(hy, hy_m), false, zke, lke, AxZ{}, 0, cz, step, ap->phE[0][2], ap->phEn[0][2], kpc, 0, mpar, st, fam == 3, pre0);
-                if (pl_in) uterm(fast, Plus{}, dd[0], diff<T, V>(hz, hz_jm), false, zye, lye, AxY{}, 0, cy, step, ap->phE[0][1], ap->phEn[0][1], kpc, 1, mpar, st, fam == 2, pre0);
+                if (row_lt) uterm(fast, Minus{}, dd[0], diff<T, V>(hy, hy_m), false, zke, lke, AxZ{}, 0, cz, step, ap->phE[0][2], ap->phEn[0][2], kpc, 0, mpar, st, fam_is(fam, 3), pre0);
+                if (pl_in) uterm(fast, Plus{}, dd[0], diff<T, V>(hz, hz_jm), false, zye, lye, AxY{}, 0, cy, step, ap->phE[0][1], ap->phEn[0][1], kpc, 1, mpar, st, fam_is(fam, 2), pre0);
                 if (((a.src_on >> step) & 1) && k == a.kJ) {
                     const P m = ldg<T, V>(a.mag + (size_t)j * px + c0, lc);
                     const T jx = step == 0 ? a.jx : a.jx2;
@@ -289,12 +293,12 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
                     for (int e = 0; e < V; ++e) dd[0].v[e] = dd[0].v[e] + jx * m.v[e];
                 }
                 if (row_lt) {
-                    uterm(fast, Plus{}, dd[1], diff<T, V>(hx, hx_m), first, zke, lke, AxZ{}, 0, cz, step, ap->phE[1][2], ap->phEn[1][2], kpc, 2, mpar, st, fam == 3, pre1);
+                    uterm(fast, Plus{}, dd[1], diff<T, V>(hx, hx_m), first, zke, lke, AxZ{}, 0, cz, step, ap->phE[1][2], ap->phEn[1][2], kpc, 2, mpar, st, fam_is(fam, 3), pre1);
                     if (pl_in) xterm(fast, Minus{}, dd[1], diff_back_x<T, V>(hz, hz_l), 0, xcd, step, pre0, ap->phEn[1][0], kpc, 3, mpar, st);
                 }
                 if (pl_lt) {
                     if (row_in) xterm(fast, Plus{}, dd[2], diff_back_x<T, V>(hy, hy_l), 0, xcd, step, pre1, ap->phEn[2][0], kpc, 4, mpar, st);
-                    uterm(fast, Minus{}, dd[2], diff<T, V>(hx, hx_jm), first, zye, lye, AxY{}, 0, cy, step, ap->phE[2][1], ap->phEn[2][1], kpc, 5, mpar, st, fam == 2, pre1);
+                    uterm(fast, Minus{}, dd[2], diff<T, V>(hx, hx_jm), first, zye, lye, AxY{}, 0, cy, step, ap->phE[2][1], ap->phEn[2][1], kpc, 5, mpar, st, fam_is(fam, 2), pre1);
                 }
             };
             // most waves are nowhere near a layer: they take the straight-line code of the kernel without CPML
@@ -312,15 +316,15 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             const int kpc = kp < 0 ? 0 : (kp < a.nzp ? kp : a.nzp - 1);
             auto terms = [&](auto fast) {
                 if (row_lt && bl_lt) {
-                    uterm(fast, Plus{}, bb[0], diff<T, V>(e_kp[1], e[1]), first, zkh, lkh, AxZ{}, 3, cz, step, ap->phM[0][2], ap->phMn[0][2], kpc, 6, mpar, st, fam == 3, pre0);
-                    uterm(fast, Minus{}, bb[0], diff<T, V>(ez_jp, e[2]), first, zyh, lyh, AxY{}, 3, cy, step, ap->phM[0][1], ap->phMn[0][1], kpc, 7, mpar, st, fam == 2, pre0);
+                    uterm(fast, Plus{}, bb[0], diff<T, V>(e_kp[1], e[1]), first, zkh, lkh, AxZ{}, 3, cz, step, ap->phM[0][2], ap->phMn[0][2], kpc, 6, mpar, st, fam_is(fam, 3), pre0);
+                    uterm(fast, Minus{}, bb[0], diff<T, V>(ez_jp, e[2]), first, zyh, lyh, AxY{}, 3, cy, step, ap->phM[0][1], ap->phMn[0][1], kpc, 7, mpar, st, fam_is(fam, 2), pre0);
                 }
                 if (bl_lt && row_in) {
                     xterm(fast, Plus{}, bb[1], diff_fwd_x<T, V>(e[2], ez_r), 3, xch, step, pre0, ap->phMn[1][0], kpc, 8, mpar, st);
-                    uterm(fast, Minus{}, bb[1], diff<T, V>(e_kp[0], e[0]), false, zkh, lkh, AxZ{}, 3, cz, step, ap->phM[1][2], ap->phMn[1][2], kpc, 9, mpar, st, fam == 3, pre1);
+                    uterm(fast, Minus{}, bb[1], diff<T, V>(e_kp[0], e[0]), false, zkh, lkh, AxZ{}, 3, cz, step, ap->phM[1][2], ap->phMn[1][2], kpc, 9, mpar, st, fam_is(fam, 3), pre1);
                 }
                 if (row_lt && bl_in) {
-                    uterm(fast, Plus{}, bb[2], diff<T, V>(ex_jp, e[0]), false, zyh, lyh, AxY{}, 3, cy, step, ap->phM[2][1], ap->phMn[2][1], kpc, 10, mpar, st, fam == 2, pre1);
+                    uterm(fast, Plus{}, bb[2], diff<T, V>(ex_jp, e[0]), false, zyh, lyh, AxY{}, 3, cy, step, ap->phM[2][1], ap->phMn[2][1], kpc, 10, mpar, st, fam_is(fam, 2), pre1);
                     xterm(fast, Minus{}, bb[2], diff_fwd_x<T, V>(e[1], ey_r), 3, xch, step, pre1, ap->phMn[2][0], kpc, 11, mpar, st);
                 }
             };
@@ -402,18 +406,19 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
                 for (int c = 0; c < 3; ++c) h1[c] = h_of(b1[c], mu_km[c]);
                 lds_st<T, V>(slot(h1s, par, w), h1[0]); lds_st<T, V>(slot(h1s, par, w) + TW, h1[2]);
             }
+            // the state the second-step terms of this iteration continue from (left in `mid` one iteration ago): requested
+            // before the barrier, so that the wait for the other waves covers its way from L2
+            int lkC, lkD;
+            const int zkC = zone_e(k - 1, Nz, a.np[2][0], a.np[2][1], lkC), zkD = zone_h(k - 2, Nz, a.np[2][0], a.np[2][1], true, lkD);
+            const int famC = (LAYERS && kl >= kb + 1) ? family(y_layer_e, zkC) : 0, famD = (LAYERS && kl >= kb + 2) ? family(y_layer_h, zkD) : 0;
+            const P preC0 = request(famC, false, 0, 1, 0, zkC, lkC, par ^ 1), preC1 = request(famC, false, 1, 1, 0, zkC, lkC, par ^ 1);
+            const P preD0 = request(famD, true, 0, 1, 0, zkD, lkD, par), preD1 = request(famD, true, 1, 1, 0, zkD, lkD, par);
             __syncthreads();
 
             // ------------------------------------------------------------ C: D2(k-1), E2(k-1)
             P e2[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) e2[c] = zero_pack<T, V>();
-            // the state the second-step terms of this iteration continue from (left in `mid` one iteration ago)
-            int lkC, lkD;
-            const int zkC = zone_e(k - 1, Nz, a.np[2][0], a.np[2][1], lkC), zkD = zone_h(k - 2, Nz, a.np[2][0], a.np[2][1], true, lkD);
-            const int famC = (LAYERS && kl >= kb + 1) ? family(y_layer_e, zkC) : 0, famD = (LAYERS && kl >= kb + 2) ? family(y_layer_h, zkD) : 0;
-            const P preC0 = request(famC, false, 0, 1, 0, zkC, lkC, par ^ 1), preC1 = request(famC, false, 1, 1, 0, zkC, lkC, par ^ 1);
-            const P preD0 = request(famD, true, 0, 1, 0, zkD, lkD, par), preD1 = request(famD, true, 1, 1, 0, zkD, lkD, par);
             if (kl >= kb + 1) {
                 asm volatile("" : "+s"(ap));
                 const T* dn = slot(h1s, par, w_dn);                  // H1(k-1) of the row below, published before the barrier
