@@ -271,7 +271,7 @@ int fdtd3d_launch_shape(fdtd3d_handle h, int out[6]);
 
 /* Timing hook for the dominant kernels: if enabled, every E-half / H-half launch is
  * bracketed by HIP events on its stream; fdtd3d_kernel_time() synchronises and returns
- * the launch count and the summed device time (ms) per kernel kind (0 = E, 1 = H, 2 = fused). */
+ * the launch count and the summed device time (ms) per kernel kind (0 = E, 1 = H, 2 = fused step, 3 = two steps per launch). */
 int fdtd3d_kernel_timing(fdtd3d_handle h, int enable);
 int fdtd3d_kernel_time(fdtd3d_handle h, int kind, int* launches, double* total_ms);
 /* The launches timed since the last fdtd3d_kernel_time() call of their kind, in launch order: kind as
