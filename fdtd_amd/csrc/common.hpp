@@ -61,6 +61,7 @@ int entry(H h, F&& body) {
 }
 
 // ---- device vocabulary ------------------------------------------------------------------
+#define FDTD_AS(n) __attribute__((address_space(n)))   // 1: global, 4: constant (read through the scalar cache)
 constexpr int kLanes = 64;        // CDNA wavefront
 constexpr int kRowAlign = 256;    // row pitch granule in elements: one wave row of 16-byte lanes (fp32)
 constexpr int kMaxLayers = 64;    // CPML layers per face the table storage admits

@@ -130,7 +130,8 @@ __device__ __forceinline__ void apply_uniform(Pack<T, V>& d, const Pack<T, V>& c
                                               const T* __restrict__ face, int kb, T cmid, T dt, T* phi_n, T* phi_p) {
     if (mask == 0u || zone == Z_NONE) return;
     if (zone == Z_MID) { apply_mid<SIGN, T, V>(d, curl, mask, cmid); return; }
-    const T* t = face + (zone == Z_POS ? 6 * kMaxLayers : 0) + kb * kMaxLayers + l;
+    // (tables through the scalar cache: the layer is the same for the whole wave)
+    const FDTD_AS(4) T* t = (const FDTD_AS(4) T*)(face + (zone == Z_POS ? 6 * kMaxLayers : 0) + kb * kMaxLayers + l);
     apply_pml<SIGN, T, V>(d, curl, mask, t[0], t[kMaxLayers], t[2 * kMaxLayers], dt, zone == Z_POS ? phi_p : phi_n);
 }
 // Term along x: the zone changes from element to element.  Coefficients come from rows expanded
@@ -237,7 +238,7 @@ __device__ __forceinline__ void term_u(Pack<T, V>& d, const Pack<T, V>& curl, bo
 #pragma unroll
         for (int e = 0; e < V; ++e) { const T v = cmid * curl.v[e]; d.v[e] = SIGN > 0 ? d.v[e] + v : d.v[e] - v; }
     } else {
-        const T* t = face + (zone == Z_POS ? 6 * kMaxLayers : 0) + kb * kMaxLayers + l;
+        const FDTD_AS(4) T* t = (const FDTD_AS(4) T*)(face + (zone == Z_POS ? 6 * kMaxLayers : 0) + kb * kMaxLayers + l);
         const T b = t[0], a = t[kMaxLayers], C = t[2 * kMaxLayers];
         T* phi = zone == Z_POS ? phi_p : phi_n;
         Pack<T, V> ph = ldv<T, V>(phi);

@@ -30,7 +30,6 @@ namespace fdtd {
 // global address space.  The kernel argument block is re-read through a pointer pinned once per
 // plane, so that the several dozen array pointers are fetched (scalar cache) where they are needed
 // instead of living in registers across the loop.
-#define FDTD_AS(n) __attribute__((address_space(n)))
 
 template <typename T, int V>
 __device__ __forceinline__ Pack<T, V> ldg(const T* ubase, unsigned lo) {
@@ -88,7 +87,9 @@ __device__ __forceinline__ void term_u2(Pack<T, V>& d, const Pack<T, V>& curl, b
         for (int e = 0; e < V; ++e) { const T v = cmid * curl.v[e]; d.v[e] = SIGN > 0 ? d.v[e] + v : d.v[e] - v; }
     } else {
         const int side = zone == Z_POS;
-        const T* t = face + side * 6 * kMaxLayers + kb * kMaxLayers + l;
+        // (through the scalar cache: the layer is the same for the whole wave, and a vector load would make the term wait
+        // for every load the wave has in flight)
+        const FDTD_AS(4) T* t = (const FDTD_AS(4) T*)(face + side * 6 * kMaxLayers + kb * kMaxLayers + l);
         const T b = t[0], a = t[kMaxLayers], C = t[2 * kMaxLayers];
         const size_t off = side ? off_p : off_n;
         Pack<T, V> ph = ldg<T, V>(in[side] + off, lo);
@@ -114,7 +115,7 @@ __device__ __forceinline__ void term_u1(T& d, T curl, int zone, int l, const T* 
     if (zone == Z_MID) v = cmid * curl;
     else {
         const int side = zone == Z_POS;
-        const T* t = face + side * 6 * kMaxLayers + l;
+        const FDTD_AS(4) T* t = (const FDTD_AS(4) T*)(face + side * 6 * kMaxLayers + l);
         const T p = t[0] * ldg1<T>(in[side] + (side ? off_p : off_n)) + t[kMaxLayers] * curl;
         v = t[2 * kMaxLayers] * curl + dt * p;
     }

@@ -72,7 +72,9 @@ __device__ __forceinline__ void pair_axpy_x(Pack<T, V>& d, const Pack<T, V>& c, 
 // of this layer on the low side of the axis; the high side follows 6 tables further.
 template <int SIGN, typename T, int V>
 __device__ __forceinline__ void pair_cpml_u(Pack<T, V>& d, const Pack<T, V>& curl, bool skip0, bool high, const T* __restrict__ t, T dt, Pack<T, V>& ph) {
-    const T* tt = t + (high ? 6 * kMaxLayers : 0);
+    // the tables are read through the scalar cache (the layer is the same for the whole wave): a vector load here would
+    // make the term wait for every load the wave has in flight
+    const FDTD_AS(4) T* tt = (const FDTD_AS(4) T*)(t + (high ? 6 * kMaxLayers : 0));
     const T b = tt[0], a = tt[kMaxLayers], C = tt[2 * kMaxLayers];
     const T d0 = d.v[0], p0 = ph.v[0];
 #pragma unroll
