@@ -1245,7 +1245,6 @@ struct Engine3 : fdtd3d_engine {
         if (d.z_lo != 0 || d.z_hi != d.Nz) return fail(FDTD_ERR_STATE, "two-step launches need the whole grid on this device");
         bool pml = false;
         for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) pml = pml || np[ax][sd] != 0;
-        if (getenv("FDTD_PAIR_FORCE_PML")) pml = true;        // experiment: the CPML-capable kernel on a grid without layers
         for (int m = 0; m < 2; ++m) for (int c = 0; c < 3; ++c) for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd)
             if (phSize[m][c][ax][sd] >= ((size_t)1 << 31)) return fail(FDTD_ERR_STATE, "two-step launches index the CPML state with 32 bits: an array of %zu elements is too large", phSize[m][c][ax][sd]);
         if (phase != 0) return fail(FDTD_ERR_STATE, "two-step launch in the middle of a split step");
