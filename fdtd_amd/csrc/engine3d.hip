@@ -266,6 +266,8 @@ struct fdtd3d_engine {
     virtual int halo(int which, int comp, void** p, size_t* bytes, int at_parity) = 0;
     virtual int reduce(int id, double* sumsq, uint64_t* checksum, hipStream_t s) = 0;
     virtual int reduce_static(const int* ids, int n_ids, double* sumsq, uint64_t* checksum, hipStream_t s) = 0;
+    virtual int reduce_range(int id, int k_lo, int k_hi, double* sumsq, uint64_t* checksum, hipStream_t s) = 0;
+    virtual int planes(int id, int k, int count, void** p, size_t* nbytes) = 0;
     virtual size_t device_bytes() = 0;
     virtual int tune(int chunk, int remap, int rows) = 0;
     virtual void launch_shape(int out[6]) = 0;
@@ -982,6 +984,38 @@ struct Engine3 : fdtd3d_engine {
         return FDTD_OK;
     }
 
+    // the same over the global planes [k_lo, k_hi) only (a slab that stores more layers than it answers for)
+    int reduce_range(int id, int k_lo, int k_hi, double* sumsq, uint64_t* checksum, hipStream_t s) override {
+        if (id < 0 || id >= 18 || !fld[id]) return fail(FDTD_ERR_ARG, "reduce: array %d is not a resident field", id);
+        CompGeom g = geom(id, true);
+        g.kl_lo = std::max(g.kl_lo, k_lo - zoff);
+        g.kl_hi = std::min(g.kl_hi, k_hi - zoff);
+        if (g.kl_hi < g.kl_lo) g.kl_hi = g.kl_lo;
+        FDTD_HIP(hipMemsetAsync(red_d, 0, 1025 * sizeof(double), s));
+        hipLaunchKernelGGL(k_reduce<T>, dim3(kReduceBlocks), dim3(256), 0, s, fld[id], g, red_d, (unsigned long long*)(red_d + kReduceBlocks));
+        FDTD_HIP(hipGetLastError());
+        std::vector<double> h(1025);
+        FDTD_HIP(hipMemcpyAsync(h.data(), red_d, 1025 * sizeof(double), hipMemcpyDeviceToHost, s));
+        FDTD_HIP(hipStreamSynchronize(s));
+        double acc = 0;
+        for (int q = 0; q < 1024; ++q) acc += h[q];
+        if (sumsq) *sumsq = acc;
+        if (checksum) std::memcpy(checksum, &h[1024], sizeof(uint64_t));
+        return FDTD_OK;
+    }
+    // `count` consecutive stored planes of a D / B array or of an x- or y-face CPML array, starting at global plane k,
+    // in the buffers that are current now: pointer arithmetic only
+    int planes(int id, int k, int count, void** p, size_t* nbytes) override {
+        Map m;
+        if (!make_map(id, m) || !m.dev || (m.kind != 0 && m.kind != 2 && m.kind != 3)) return fail(FDTD_ERR_ARG, "planes: array %d has no per-plane storage here", id);
+        const int kl = k - zoff;
+        if (count < 1 || kl < 0 || kl + count > nzp) return fail(FDTD_ERR_ARG, "planes: [%d, %d) is not stored by this slab", k, k + count);
+        const size_t per = m.kind == 0 ? plane : (m.kind == 2 ? (size_t)np[1][m.s] * px : (size_t)ny1 * (m.s ? xwp : xwn));
+        *p = m.dev + (size_t)kl * per;
+        *nbytes = (size_t)count * per * sizeof(T);
+        return FDTD_OK;
+    }
+
     // The same reduction for up to kStaticMaxIds arrays in one call, with the partial sums in the file-scope
     // scratch array: no hipMalloc, no hipFree, no host container.  One stream synchronisation at the end.
     int reduce_static(const int* ids, int n_ids, double* sumsq, uint64_t* checksum, hipStream_t s) override {
@@ -1242,7 +1276,6 @@ struct Engine3 : fdtd3d_engine {
     void pair_info(int out[4]) override { out[0] = pair_auto() ? 1 : 0; out[1] = pair_chunk(); out[2] = wpbp; out[3] = V / 2; }
     int step_pair(int n, hipStream_t s) override {
         if (!fused) return fail(FDTD_ERR_STATE, "two-step launches need an engine created with FDTD3D_MODE_FUSED");
-        if (d.z_lo != 0 || d.z_hi != d.Nz) return fail(FDTD_ERR_STATE, "two-step launches need the whole grid on this device");
         bool pml = false;
         for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) pml = pml || np[ax][sd] != 0;
         for (int m = 0; m < 2; ++m) for (int c = 0; c < 3; ++c) for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd)
@@ -1268,11 +1301,11 @@ struct Engine3 : fdtd3d_engine {
         a.wpb = wpbp;
         a.nby = (ny1 + (wpbp - 3) - 1) / (wpbp - 3);
         a.chunk = pair_chunk();
-        a.kl0 = 1; a.kl1 = nzp;
+        a.kl0 = 1; a.kl1 = last_rank ? nzp : nzp - 1;         // the owned planes (on a slab: see fdtd3d_step_pairs)
         // chunks that come near the z layers (within the four planes a chunk looks below itself, the one above) are cut
-        // separately: everything else then runs the loop without z-layer code
-        a.zcut[0] = np[2][0] > 0 ? std::min(np[2][0] + 5, a.kl1) : a.kl0;
-        a.zcut[1] = np[2][1] > 0 ? std::max(a.zcut[0], d.Nz - np[2][1] - 1) : a.kl1;
+        // separately: everything else then runs the loop without z-layer code.  Local plane = global plane - zoff.
+        a.zcut[0] = np[2][0] > 0 ? std::max(a.kl0, std::min(np[2][0] + 4 - zoff, a.kl1)) : a.kl0;
+        a.zcut[1] = np[2][1] > 0 ? std::min(a.kl1, std::max(a.zcut[0], d.Nz - np[2][1] - 2 - zoff)) : a.kl1;
         const int len[3] = {a.zcut[0] - a.kl0, a.zcut[1] - a.zcut[0], a.kl1 - a.zcut[1]};
         int nb[3];
         for (int q = 0; q < 3; ++q) {
@@ -1451,6 +1484,13 @@ int fdtd3d_halo_at(fdtd3d_handle h, int parity, int which, int comp, void** p, s
 }
 int fdtd3d_sumsq(fdtd3d_handle h, int id, double* out, void* stream) { return entry(h, [&] { return h->reduce(id, out, nullptr, (hipStream_t)stream); }); }
 int fdtd3d_checksum(fdtd3d_handle h, int id, uint64_t* out, void* stream) { return entry(h, [&] { return h->reduce(id, nullptr, out, (hipStream_t)stream); }); }
+int fdtd3d_reduce_range(fdtd3d_handle h, int id, int k_lo, int k_hi, double* sumsq, uint64_t* checksum, void* stream) {
+    return entry(h, [&] { return h->reduce_range(id, k_lo, k_hi, sumsq, checksum, (hipStream_t)stream); });
+}
+int fdtd3d_planes(fdtd3d_handle h, int id, int k, int count, void** p, size_t* bytes) {
+    if (!h || !p || !bytes) return fail(FDTD_ERR_ARG, "null argument");
+    return h->planes(id, k, count, p, bytes);          // pointer arithmetic only: no device call
+}
 int fdtd3d_reduce_static(fdtd3d_handle h, const int* ids, int n_ids, double* sumsq, uint64_t* checksum, void* stream) {
     return entry(h, [&] { return h->reduce_static(ids, n_ids, sumsq, checksum, (hipStream_t)stream); });
 }

@@ -198,6 +198,19 @@ class Engine3D(_Common):
         """Steps n0 .. n0+2*pairs-1, two per launch (fdtd3d_step_pairs: no CPML, whole grid, FUSED mode, no probes)."""
         _check(lib().fdtd3d_step_pairs(self.h, C.c_int(n0), C.c_int(pairs), _stream_handle(stream)), "fdtd3d_step_pairs")
 
+    def planes(self, id_: int, k: int, count: int = 1):
+        """(device pointer, bytes) of `count` stored planes of array `id_` from global plane k, current buffers."""
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(lib().fdtd3d_planes(self.h, C.c_int(id_), C.c_int(k), C.c_int(count), C.byref(p), C.byref(n)), "fdtd3d_planes")
+        return p.value, n.value
+
+    def reduce_range(self, id_: int, k_lo: int, k_hi: int, stream=None):
+        """(sum of squares, checksum) of array `id_` over the owned planes inside the global range [k_lo, k_hi)."""
+        ss, cs = C.c_double(), C.c_uint64()
+        _check(lib().fdtd3d_reduce_range(self.h, C.c_int(id_), C.c_int(k_lo), C.c_int(k_hi), C.byref(ss), C.byref(cs),
+                                         _stream_handle(stream)), "fdtd3d_reduce_range")
+        return ss.value, cs.value
+
     def pair_info(self) -> dict:
         """Whether step() goes two steps per launch on this engine, and the two-step kernel's launch shape."""
         o = (C.c_int * 4)()
@@ -454,6 +467,14 @@ class _DeviceSpan:
     def __init__(self, ptr: int, nbytes: int, itemsize: int):
         self.__cuda_array_interface__ = {"shape": (nbytes // itemsize,), "typestr": "<f4" if itemsize == 4 else "<f8",
                                          "data": (ptr, False), "version": 2}
+
+
+def planes_tensor(engine: "Engine3D", id_: int, k: int, count: int = 1):
+    """torch tensor aliasing `count` stored planes of array `id_` from global plane k (current buffers; no copy)."""
+    import torch
+    ptr, nbytes = engine.planes(id_, k, count)
+    itemsize = 4 if engine.precision == 32 else 8
+    return torch.as_tensor(_DeviceSpan(ptr, nbytes, itemsize), device=torch.device("cuda", torch.cuda.current_device()))
 
 
 def halo_tensor(engine: "Engine3D", which: int, comp: int, parity=None):

@@ -190,6 +190,93 @@ class SlabStepper:
         self._pending_h = []
 
 
+def pair_slab_range(z_lo: int, z_hi: int, Nz: int) -> Tuple[int, int]:
+    """Layers a rank has to STORE to advance its layers [z_lo, z_hi) two steps per launch: one more either side of
+    every cut (see PairSlabStepper)."""
+    return max(0, z_lo - 1), min(Nz, z_hi + 1)
+
+
+def pair_slabs_possible(parts: Sequence[Tuple[int, int]], Nz: int, npml_z: Tuple[int, int]) -> bool:
+    """Every slab at least two layers thick, every cut clear of the z layers by the planes that cross it."""
+    cuts = [lo for lo, _ in parts[1:]]
+    return all(hi - lo >= 2 for lo, hi in parts) and all(c - 2 > npml_z[0] + 1 and c + 2 < Nz - npml_z[1] - 1 for c in cuts)
+
+
+class PairSlabStepper:
+    """One rank's time loop with two time steps per kernel launch (fdtd3d_step_pairs on a slab).
+
+    The kernel recomputes its halos from what the slab stores, and next to a cut the slab's single ghost plane
+    cannot feed a second step: after a launch everything is exact except the outermost stored layer either side
+    and the ghost planes.  So neighbouring slabs overlap: this rank stores [z_lo-1, z_hi+1) (`pair_slab_range`),
+    answers for [z_lo, z_hi), and after every launch the two planes beyond each cut -- D, B and the x- and y-face
+    CPML state of both families -- are overwritten with the neighbour's exact ones: planes z_hi-2, z_hi-1 go up,
+    planes z_lo, z_lo+1 go down (each a contiguous device range per array).  One exchange per two steps instead of
+    two per step; nothing overlaps it yet (the whole launch has to finish before its edge planes exist).  An odd
+    step at the end is one launch of the one-step kernel followed by the same exchange.
+
+    `engine` needs step_pairs(n, 1), fused(n, part), parity() and planes via `tensor_of(engine, id, k, count)`.
+    """
+
+    def __init__(self, engine, rank: int, world: int, own: Tuple[int, int], ids: Sequence[int], tensor_of, group=None, stream=None):
+        self.engine, self.rank, self.world, self.own, self.ids = engine, rank, world, own, list(ids)
+        self.tensor_of, self.group, self.stream = tensor_of, group, stream
+        self._x = {}                      # HaloExchange per set of current buffers
+        self._singles = 0                 # one-step launches so far: they swap D and B but not the B-side CPML buffers
+
+    def _exchange(self) -> None:
+        e = self.engine
+        key = (e.parity(), self._singles & 1)
+        if key not in self._x:
+            lo, hi = self.own
+            up, down = self.rank + 1 < self.world, self.rank > 0
+            t = lambda k: [self.tensor_of(e, id_, k, 2) for id_ in self.ids]
+            self._x[key] = HaloExchange(self.rank, self.world, t(hi - 2) if up else [], t(lo - 2) if down else [],
+                                        t(lo) if down else [], t(hi) if up else [], self.group)
+        x = self._x[key]
+        reqs = x.start_up() + x.start_down()
+        HaloExchange.wait(reqs)
+
+    def pair(self, n: int) -> None:
+        self.engine.step_pairs(n, 1, self.stream)
+        self._exchange()
+
+    def single(self, n: int) -> None:
+        self.engine.fused(n, PART_ALL, self.stream)
+        self._singles += 1
+        self._exchange()
+
+    def prime(self) -> None:
+        """One exchange before the first step: sets the point-to-point channels up outside any timed region (the
+        planes carry the initial state, which is what both sides hold anyway)."""
+        self._exchange()
+
+    def run(self, n0: int, count: int) -> None:
+        n = n0
+        for _ in range(count // 2):
+            self.pair(n)
+            n += 2
+        if count % 2:
+            self.single(n)
+
+    def finish(self) -> None:
+        pass
+
+
+def make_gpu_pair_stepper(engine, rank: int, world: int, own: Tuple[int, int], group=None, stream=None):
+    """PairSlabStepper over an Engine3D created with z_range = pair_slab_range(*own, Nz): the exchanged arrays are
+    D, B and every x- and y-face CPML array the engine holds."""
+    from .engine import BX, DX, PHI_E, PHI_M, planes_tensor
+    ids = [DX + c for c in range(3)] + [BX + c for c in range(3)]
+    for base in (PHI_E, PHI_M):
+        for comp in range(3):
+            for axis in (0, 1):
+                for side in (0, 1):
+                    id_ = base + (comp * 3 + axis) * 2 + side
+                    if axis != comp and engine.size(id_):
+                        ids.append(id_)
+    return PairSlabStepper(engine, rank, world, own, ids, planes_tensor, group, stream)
+
+
 def make_gpu_stepper(engine, rank: int, world: int, group=None, stream=None):
     """Wire an Engine3D's own ghost planes into a stepper (tensors alias engine memory): a
     FusedSlabStepper for MODE_FUSED engines, a SlabStepper otherwise."""

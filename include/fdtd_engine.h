@@ -135,15 +135,27 @@ int fdtd3d_step(fdtd3d_handle h, int n0, int count, void* stream);
 /* Steps n0 .. n0 + 2*pairs - 1 with TWO steps per launch (updateE, updateH, updateE, updateH of
  * FDTD3D.cpp:480-1021 for a cell before its neighbours' second step is due): D, B, eps and mu cross
  * device memory once per two steps; the results are those of 2*pairs calls of the one-step kernel, bit
- * for bit, CPML state included.  Restricted to what the kernel carries so far: FUSED mode, the whole
- * grid on this device, no probes registered (a probe would have to be sampled between the two steps of
- * a launch).  Anything else is refused with FDTD_ERR_STATE.  fdtd3d_step uses these launches by itself
- * for as many of its steps as it can when the grid is large enough for them to pay (384^3 cells; the
- * environment variable FDTD_PAIR=0/1 overrides) and no probe is registered.
+ * for bit, CPML state included.  Restricted to what the kernel carries so far: FUSED mode, no probes
+ * registered (a probe would have to be sampled between the two steps of a launch); on a slab see the
+ * note on overlapping slabs below.  Anything else is refused with FDTD_ERR_STATE.  fdtd3d_step uses
+ * these launches by itself for as many of its steps as it can when the engine holds the whole grid,
+ * the grid is large enough for them to pay (384^3 cells; the environment variable FDTD_PAIR=0/1
+ * overrides) and no probe is registered.
  * fdtd3d_pair_shape sets the planes per workgroup (default: chosen from the grid, at most 128) and the
  * waves per workgroup (6..16, default 16; three of them are halo rows); 0 keeps. */
 int fdtd3d_step_pairs(fdtd3d_handle h, int n0, int pairs, void* stream);
 int fdtd3d_pair_shape(fdtd3d_handle h, int chunk, int rows);
+/* Two-step launches on a SLAB (z_lo > 0 or z_hi < Nz) are exact only two planes away from a cut: the kernel
+ * recomputes its halos from what the slab stores and the slab's single ghost plane cannot feed the second step
+ * of the plane next to it.  A slab driver therefore lets neighbouring slabs OVERLAP by one layer either side of
+ * the cut (rank r stores [z_lo-1, z_hi+1) and answers for [z_lo, z_hi)), calls fdtd3d_step_pairs(h, n, 1, ..)
+ * and then overwrites the two planes beyond each cut -- D, B and the x- and y-face CPML state, both families --
+ * with the neighbour's exact ones (fdtd3d_planes gives the device ranges; fdtd_amd/slab.py: PairSlabStepper).
+ * Cuts must stay clear of the z layers (the z-face state is not exchanged). */
+/* Device range of `count` consecutive stored planes, starting at GLOBAL plane k, of array `id` (D or B
+ * component, or an x- or y-face CPML array) in the buffers that are current now -- fetch again after every
+ * step, the buffers change roles.  Pointer arithmetic only. */
+int fdtd3d_planes(fdtd3d_handle h, int id, int k, int count, void** p, size_t* bytes);
 /* out = { 1 if fdtd3d_step takes its steps two per launch on this engine, planes per workgroup,
  *         waves per workgroup, elements per lane } of the two-step kernel. */
 int fdtd3d_pair_info(fdtd3d_handle h, int out[4]);
@@ -188,6 +200,9 @@ int fdtd3d_halo_at(fdtd3d_handle h, int parity, int which, int comp, void** dev_
 /* Sum over owned cells of the squares of array `id`, accumulated in double on device
  * (diagnostic / checksum). */
 int fdtd3d_sumsq(fdtd3d_handle h, int id, double* out, void* stream);
+/* The same two reductions over the owned planes inside the GLOBAL range [k_lo, k_hi) only (either result
+ * pointer may be NULL): for slabs that store more layers than they answer for. */
+int fdtd3d_reduce_range(fdtd3d_handle h, int id, int k_lo, int k_hi, double* sumsq, uint64_t* checksum, void* stream);
 
 /* Order-independent 64-bit checksum over owned cells of array `id` (value bits mixed with the
  * canonical cell index, summed modulo 2^64; zeros of either sign contribute nothing), for

@@ -227,3 +227,27 @@ def test_pairs_equal_single_steps_random_configurations(seed):
     for id_ in [po.DX, po.DY, po.DZ, po.BX, po.BY, po.BZ] + po.ALL_PHI3D:
         if engs[0].size(id_):
             util.assert_equal_arrays(engs[0].get(id_), engs[1].get(id_), f"{what} array {id_}")
+
+
+@pytest.mark.parametrize("ranks,env", [
+    (2, {"PAIR_PREC": "32", "PAIR_MU": "1"}),
+    (3, {"PAIR_PREC": "64", "PAIR_MU": "0", "PAIR_CHUNK": "48", "PAIR_ROWS": "16"}),
+    (3, {"PAIR_PREC": "32", "PAIR_MU": "1", "PAIR_N": "300,20,47", "PAIR_NPML": "5,6,0,3,4,4", "PAIR_STEPS": "12", "PAIR_KJ": "21"}),
+])
+def test_pair_slab_stepper_equals_whole_grid(ranks, env):
+    """Slabs that overlap by one layer either side of a cut, two steps per launch, the two planes beyond each cut
+    exchanged after every launch (gloo, all ranks on cuda:0): every rank's own layers -- D, B, x- and y-face CPML
+    state, range checksums -- equal a whole-grid engine's bit for bit (tests/helpers/pair_slab_check.py)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "helpers", "pair_slab_check.py")]
+    r = subprocess.run(cmd, cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    assert r.stdout.count(": OK") == ranks, r.stdout[-1500:]
