@@ -236,18 +236,29 @@ def main():
     d = (1053e-9 / 20,) * 3                      # the reference's cell: lambda0 / 20
     dt = d[0] / (K["c0"] * 2.0)                  # its CFL choice
     n_total = args.warmup + args.steps
-    z_lo, z_hi = slab.partition(Nz, world)[rank]
+    parts = slab.partition(Nz, world)
+    z_lo, z_hi = parts[rank]
+    # several ranks, fused storage: two steps per launch on slabs that overlap by one layer either side of a cut
+    # (slab.PairSlabStepper) unless FDTD_BENCH_STEPPER=single asks for the one-step kernels with their per-step exchanges
+    pair_slabs = (world > 1 and mode_name == "fused" and os.environ.get("FDTD_BENCH_STEPPER", "pair") != "single"
+                  and os.environ.get("FDTD_PAIR", "1") != "0" and slab.pair_slabs_possible(parts, Nz, (npml[4], npml[5])))
+    stored = slab.pair_slab_range(z_lo, z_hi, Nz) if pair_slabs else (z_lo, z_hi)
 
     eng = fdtd_amd.Engine3D((Nx, Ny, Nz), npml, d, dt, K["mu0"], 20, n_total, precision=32, has_mu=has_mu,
                             mode={"fused": fdtd_amd.engine.MODE_FUSED, "lean": fdtd_amd.engine.MODE_LEAN, "full": fdtd_amd.engine.MODE_FULL}[mode_name],
-                            z_range=(z_lo, z_hi), device=local)
+                            z_range=stored, device=local)
     fs.load_cpml3d(eng, d, dt)
     wf, mag = fs.default_source3d(Nx, Ny, n_total, d, dt)
     eng.set(fdtd_amd.engine.JX_WF, wf)
     eng.set(fdtd_amd.engine.JX_MAG, mag)
     eng.fill_materials(1234, K["eps0"], 4.0 * K["eps0"], K["mu0"], 2.0 * K["mu0"])
 
-    stepper = slab.make_gpu_stepper(eng, rank, world) if world > 1 else None
+    if world == 1:
+        stepper = None
+    elif pair_slabs:
+        stepper = slab.make_gpu_pair_stepper(eng, rank, world, (z_lo, z_hi))
+    else:
+        stepper = slab.make_gpu_stepper(eng, rank, world)
     if stepper is not None:
         stepper.prime()          # RCCL sets its point-to-point channels up here, not in a timed step
 
@@ -287,16 +298,21 @@ def main():
     launches = launch_summary(eng, args.steps)
     roof = roofline_block(eng, mode_name, has_mu, cells_local, args.steps, has_mu and n_edge == 1024 and world == 1,
                           world, Nx * Ny * Nz, el)
-    sums = [eng.sumsq(i) for i in (fdtd_amd.engine.DX, fdtd_amd.engine.BY)]
+    # reductions over the layers this rank answers for (an overlapping slab stores one more either side)
+    top = Nz + 1 if rank == world - 1 else z_hi
+    sums, csum = [], 0
+    for i in (fdtd_amd.engine.DX, fdtd_amd.engine.BY):
+        ss, cs = eng.reduce_range(i, z_lo, top)
+        sums.append(ss)
+        if i == fdtd_amd.engine.DX:
+            csum = cs                     # order-independent checksum of Dx: equal for every decomposition of the same problem
     finite = all(v == v and v < float("inf") for v in sums)
     ex_energy = sums[0]
-    # order-independent checksum of Dx over the whole grid: equal for every decomposition of the same problem
-    csum = eng.checksum(fdtd_amd.engine.DX)
     multi = None
     if world > 1:
         k = max(args.steps, 1)
         mine = {"rank": rank, "device": torch.cuda.current_device(), "device_name": torch.cuda.get_device_name(),
-                "layers": [z_lo, z_hi], "wall_ms_per_step": el_own / k * 1e3, "host_issue_ms_per_step": t_issue / k * 1e3,
+                "layers": [z_lo, z_hi], "stored_layers": list(stored), "stepper": type(stepper).__name__, "wall_ms_per_step": el_own / k * 1e3, "host_issue_ms_per_step": t_issue / k * 1e3,
                 "host_wait_ms_per_step": slab.WAIT_CLOCK["seconds"] / k * 1e3, "exchange_waits_per_step": slab.WAIT_CLOCK["calls"] / k,
                 "kernel_ms_per_step": roof["kernel_ms_per_step"], "placement_probe_ms": [round(v, 3) for v in eng.placement_probes()],
                 "checksum_dx": csum, **launches}
