@@ -209,3 +209,130 @@ def test_fused_exchange_reproduces_single_rank(tmp_path, world, chunk):
     assert np.array_equal(e, ref.E[1:Nz + 2].numpy())
     assert np.array_equal(h, ref.H[1:Nz + 1].numpy())
     assert np.abs(e).max() > 0.1
+
+
+class PairLine:
+    """Stand-in for an engine that advances two steps per launch on a slab (fdtd3d_step_pairs): the same 1-D line,
+    layers [s_lo, s_hi) stored plus one ghost plane either side, two buffer sets.  Like the kernel it recomputes what
+    it needs from what is stored -- values that would need a plane beyond the ghosts come out wrong, which is why
+    PairSlabStepper lets slabs overlap and refreshes the two planes beyond every cut.  `aux` follows E with a
+    recurrence of its own and, like the engine's B-side CPML state, changes buffers on two-step launches only."""
+
+    def __init__(self, Nz, s_lo, s_hi, kJ):
+        self.Nz, self.z_lo, self.z_hi, self.kJ = Nz, s_lo, s_hi, kJ
+        self.nzl = s_hi - s_lo
+        self.last = s_hi == Nz
+        n = self.nzl + 2
+        self.fields = [[torch.zeros(n, dtype=torch.float64) for _ in range(2)] for _ in range(2)]   # [set][E, H]
+        self.aux = [torch.zeros(n, dtype=torch.float64) for _ in range(2)]
+        self.cur, self.cur_aux = 0, 0
+
+    def parity(self):
+        return self.cur
+
+    def planes(self, id_, k, count):
+        kl = k - (self.z_lo - 1)
+        assert 0 <= kl and kl + count <= self.nzl + 2, (k, count, self.z_lo, self.z_hi)
+        arr = self.aux[self.cur_aux] if id_ == 2 else self.fields[self.cur][id_]
+        return arr[kl:kl + count]
+
+    def _one_step(self, E, H, A, n):
+        """One whole step of every stored plane from (E, H, A); neighbours outside the storage count as zero."""
+        m = E.numel()
+        E1, H1 = E.clone(), H.clone()
+        for kl in range(m):
+            k = self.z_lo - 1 + kl
+            if 1 <= k < self.Nz:
+                E1[kl] = E[kl] + 0.5 * (H[kl] - (H[kl - 1] if kl >= 1 else 0.0))
+            if k == self.kJ:
+                E1[kl] = E1[kl] + np.sin(0.3 * (n + 1))
+        for kl in range(m):
+            k = self.z_lo - 1 + kl
+            if 0 <= k < self.Nz:
+                H1[kl] = H[kl] + 0.5 * ((E1[kl + 1] if kl + 1 < m else 0.0) - E1[kl])
+        return E1, H1, 0.5 * A + E1
+
+    def _owned(self):
+        return range(1, self.nzl + 2 if self.last else self.nzl + 1)
+
+    def step_pairs(self, n, pairs, stream=None):
+        assert pairs == 1
+        E, H = self.fields[self.cur]
+        A = self.aux[self.cur_aux]
+        E1, H1, A1 = self._one_step(E, H, A, n)
+        E2, H2, A2 = self._one_step(E1, H1, A1, n + 1)
+        nE, nH = self.fields[self.cur ^ 1]
+        nA = self.aux[self.cur_aux ^ 1]
+        nE.fill_(float("nan")); nH.fill_(float("nan")); nA.fill_(float("nan"))       # ghosts of the new set: stale
+        for kl in self._owned():
+            nE[kl], nH[kl], nA[kl] = E2[kl], H2[kl], A2[kl]
+        self.cur ^= 1
+        self.cur_aux ^= 1
+
+    def fused(self, n, part, stream=None):
+        assert part == slab.PART_ALL
+        E, H = self.fields[self.cur]
+        A = self.aux[self.cur_aux]
+        E1, H1, A1 = self._one_step(E, H, A, n)
+        nE, nH = self.fields[self.cur ^ 1]
+        nE.fill_(float("nan")); nH.fill_(float("nan"))
+        for kl in self._owned():
+            nE[kl] = E1[kl]
+            nH[kl] = H[kl] if (kl == self.nzl and not self.last) else H1[kl]     # top layer of a slab below another: left as it was
+            A[kl] = A1[kl]                                                       # in place
+        self.cur ^= 1
+
+
+def _pair_worker(rank, world, port, Nz, runs, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    parts = slab.partition(Nz, world)
+    own = parts[rank]
+    s_lo, s_hi = slab.pair_slab_range(own[0], own[1], Nz)
+    eng = PairLine(Nz, s_lo, s_hi, kJ=3)
+    st = slab.PairSlabStepper(eng, rank, world, own, [0, 1, 2], lambda e, id_, k, count: e.planes(id_, k, count))
+    st.prime()
+    n = 0
+    for count in runs:
+        st.run(n, count)
+        n += count
+    st.finish()
+    top = own[1] + (1 if eng.last else 0)
+    got = [eng.planes(id_, own[0], (top if id_ == 0 else own[1]) - own[0]).clone().numpy() for id_ in (0, 1, 2)]
+    # after the last exchange the planes beyond the cuts hold the neighbours' values, not leftovers
+    stored_ok = all(bool(torch.isfinite(eng.planes(id_, s_lo - (1 if rank else 0), 1)).all()) for id_ in (0, 1, 2))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (got, stored_ok))
+    if rank == 0:
+        assert all(g[1] for g in gathered)
+        for q, name in enumerate("eha"):
+            np.save(out + f"_{name}.npy", np.concatenate([g[0][q] for g in gathered]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,runs", [(2, [8, 5, 4]), (3, [3, 6, 7]), (2, [1, 1, 2])])
+def test_pair_exchange_reproduces_single_rank(tmp_path, world, runs):
+    """Two steps per launch on overlapping slabs: pairs, odd steps in between (the buffer sets then change roles
+    unevenly), several ranks -- equal to one rank stepping the whole line one step at a time."""
+    Nz = 29
+    ref = Line(Nz, 0, Nz, kJ=3)
+    aux = torch.zeros(Nz + 2, dtype=torch.float64)
+    for n in range(sum(runs)):
+        ref.half_e(n, slab.PART_ALL)
+        ref.half_h(slab.PART_ALL)
+        aux = 0.5 * aux + ref.E
+    out = str(tmp_path / "pslab")
+    mp.spawn(_pair_worker, args=(world, _free_port(), Nz, runs, out), nprocs=world, join=True)
+    e, h, a = (np.load(out + f"_{c}.npy") for c in "eha")
+    assert np.array_equal(e, ref.E[1:Nz + 2].numpy())
+    assert np.array_equal(h, ref.H[1:Nz + 1].numpy())
+    assert np.array_equal(a[:Nz], aux[1:Nz + 1].numpy())
+    assert np.abs(e).max() > 0.1
+
+
+def test_pair_slabs_possible_and_ranges():
+    assert slab.pair_slab_range(0, 10, 40) == (0, 11) and slab.pair_slab_range(10, 20, 40) == (9, 21) and slab.pair_slab_range(30, 40, 40) == (29, 40)
+    assert slab.pair_slabs_possible([(0, 128), (128, 256), (256, 384)], 384, (20, 20))
+    assert not slab.pair_slabs_possible([(0, 20), (20, 384)], 384, (20, 20))        # the cut lies in the low z layers
+    assert not slab.pair_slabs_possible([(0, 1), (1, 40)], 40, (0, 0))              # a slab of one layer
