@@ -46,5 +46,24 @@ for n in range(12):
 torch.cuda.synchronize()
 assert float(cur[E.HALO_SEND_DOWN][0].abs().max()) > 0, "nothing propagated: the exchange was not exercised"
 assert np.isfinite(eng.sumsq(E.DX))
+
+# The two-steps-per-launch stepper's messages: two consecutive planes of D, B and of the x- and y-face CPML arrays, taken
+# with fdtd3d_planes from whichever buffers are current after a two-step launch.  Sent to itself: planes z_lo, z_lo+1
+# land in the planes beyond the upper cut (z_hi, z_hi+1), as the upper neighbour's would.
+from fdtd_amd import slab  # noqa: E402
+own = (9, 23)
+st = slab.make_gpu_pair_stepper(eng, 0, 1, own)
+assert len(st.ids) > 6, "the CPML arrays are part of the exchange"
+for n in range(12, 20, 2):
+    eng.step_pairs(n, 1)
+    send = [E.planes_tensor(eng, id_, own[0], 2) for id_ in st.ids]
+    recv = [E.planes_tensor(eng, id_, own[1], 2) for id_ in st.ids]
+    reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, t, 0) for t in send] + [dist.P2POp(dist.irecv, t, 0) for t in recv])
+    for r in reqs:
+        r.wait()
+    for q, (a, b) in enumerate(zip(send, recv)):
+        assert torch.equal(a, b), f"two-step launch at {n}: planes of array {st.ids[q]} did not arrive"
+torch.cuda.synchronize()
+assert float(send[0].abs().max()) > 0
 dist.destroy_process_group()
 print("OK")
