@@ -251,6 +251,7 @@ struct fdtd3d_engine {
     virtual int step(int n, hipStream_t s) = 0;
     virtual int fused_part(int n, int part, hipStream_t s) = 0;
     virtual int step_pair(int n, hipStream_t s) = 0;
+    virtual int step_pair_part(int n, int part, hipStream_t s) = 0;
     virtual int pair_shape(int chunk, int rows) = 0;
     virtual bool pair_auto() = 0;
     virtual void pair_give_up() = 0;
@@ -1274,14 +1275,59 @@ struct Engine3 : fdtd3d_engine {
     }
     void pair_give_up() override { pair_off = true; (void)hipGetLastError(); }      // the failed allocation's error is not the next launch's
     void pair_info(int out[4]) override { out[0] = pair_auto() ? 1 : 0; out[1] = pair_chunk(); out[2] = wpbp; out[3] = V / 2; }
-    int step_pair(int n, hipStream_t s) override {
+    int step_pair(int n, hipStream_t s) override { return step_pair_part(n, FDTD3D_PART_ALL, s); }
+    // One launch of the two-step kernel over the owned planes [r0, r1).
+    int pair_launch(K3<T> a, int r0, int r1, int part, bool pml, hipStream_t s) {
+        if (r1 <= r0) return FDTD_OK;
+        constexpr int PV = V / 2, TW = kLanes * PV;
+        a.kl0 = r0; a.kl1 = r1;
+        // chunks that come near the z layers (within the four planes a chunk looks below itself, the one above) are cut
+        // separately: everything else then runs the loop without z-layer code.  Local plane = global plane - zoff.
+        a.zcut[0] = np[2][0] > 0 ? std::max(a.kl0, std::min(np[2][0] + 4 - zoff, a.kl1)) : a.kl0;
+        a.zcut[1] = np[2][1] > 0 ? std::min(a.kl1, std::max(a.zcut[0], d.Nz - np[2][1] - 2 - zoff)) : a.kl1;
+        const int len[3] = {a.zcut[0] - a.kl0, a.zcut[1] - a.zcut[0], a.kl1 - a.zcut[1]};
+        int nb[3];
+        for (int q = 0; q < 3; ++q) {
+            a.zchunk[q] = (q == 1 || chunk_pair > 0) ? a.chunk : std::max(1, len[q]);      // a face segment is one chunk unless told otherwise
+            nb[q] = (len[q] + a.zchunk[q] - 1) / a.zchunk[q];
+        }
+        a.znb[0] = nb[0]; a.znb[1] = nb[1];
+        a.nbz = nb[0] + nb[1] + nb[2];
+        const unsigned nblk = (unsigned)a.nbx * a.nby * a.nbz;
+        const size_t lds = ((size_t)6 + (size_t)3 * 2 * wpbp * 2) * TW * sizeof(T);
+        const size_t scr_need = pml ? (size_t)nblk * wpbp * 24 * TW : 0;
+        if (scr_need > pair_scr_elems) {
+            // (launches of one stream run one after the other, so the new piece can replace the old one for all of them;
+            // the old piece stays with the engine until it is destroyed)
+            if (int rc = dalloc((void**)&pair_scr, scr_need * sizeof(T), 0)) return rc;
+            pair_scr_elems = scr_need;
+        }
+        a.pair_scr = pair_scr;
+        auto go = [&](auto kern) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(nblk), dim3(kLanes * wpbp), lds, s, a);
+        };
+        timer.begin(3, s, part);
+        if (pml) { if (d.has_mu) go(k3_pair<T, true, true, PV>); else go(k3_pair<T, false, true, PV>); }
+        else { if (d.has_mu) go(k3_pair<T, true, false, PV>); else go(k3_pair<T, false, false, PV>); }
+        timer.end(s);
+        FDTD_HIP(hipGetLastError());
+        return FDTD_OK;
+    }
+    // Steps n and n+1 in one launch (PART_ALL), or in two parts so that a slab driver can send its edge planes while the
+    // bulk is computed: PART_EDGE = the three lowest and the three highest owned planes (the buffers change roles here, as
+    // with fdtd3d_fused), PART_INTERIOR = the rest.
+    int pair_phase = 0;
+    static constexpr int kPairEdge = 3;
+    int step_pair_part(int n, int part, hipStream_t s) override {
         if (!fused) return fail(FDTD_ERR_STATE, "two-step launches need an engine created with FDTD3D_MODE_FUSED");
         bool pml = false;
         for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) pml = pml || np[ax][sd] != 0;
         for (int m = 0; m < 2; ++m) for (int c = 0; c < 3; ++c) for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd)
             if (phSize[m][c][ax][sd] >= ((size_t)1 << 31)) return fail(FDTD_ERR_STATE, "two-step launches index the CPML state with 32 bits: an array of %zu elements is too large", phSize[m][c][ax][sd]);
         if (phase != 0) return fail(FDTD_ERR_STATE, "two-step launch in the middle of a split step");
-        constexpr int PV = V / 2, TW = kLanes * PV;
+        if (part != FDTD3D_PART_ALL && part != FDTD3D_PART_EDGE && part != FDTD3D_PART_INTERIOR) return fail(FDTD_ERR_ARG, "two-step launch: bad part %d", part);
+        if ((part == FDTD3D_PART_INTERIOR) != (pair_phase == 1)) return fail(FDTD_ERR_STATE, "two-step launches: a pair of steps is ALL, or EDGE then INTERIOR");
         K3<T> a = args();
         const bool s1 = n >= 0 && n < (int)wf.size(), s2 = n + 1 >= 0 && n + 1 < (int)wf.size();
         a.src_on = (s1 ? 1 : 0) | (s2 ? 2 : 0);
@@ -1297,48 +1343,33 @@ struct Engine3 : fdtd3d_engine {
             a.Dn[c] = alt[c]; a.Bn[c] = alt[6 + c];
             for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) { a.phEn[c][ax][sd] = phE2[c][ax][sd]; a.phMn[c][ax][sd] = phM2[c][ax][sd]; }
         }
+        if (part == FDTD3D_PART_INTERIOR)       // the roles were exchanged when EDGE was launched
+            for (int c = 0; c < 3; ++c) {
+                std::swap(a.D[c], a.Dn[c]); std::swap(a.B[c], a.Bn[c]);
+                for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) { std::swap(a.phE[c][ax][sd], a.phEn[c][ax][sd]); std::swap(a.phM[c][ax][sd], a.phMn[c][ax][sd]); }
+            }
         a.nbx = pair_nbx();
         a.wpb = wpbp;
         a.nby = (ny1 + (wpbp - 3) - 1) / (wpbp - 3);
         a.chunk = pair_chunk();
-        a.kl0 = 1; a.kl1 = last_rank ? nzp : nzp - 1;         // the owned planes (on a slab: see fdtd3d_step_pairs)
-        // chunks that come near the z layers (within the four planes a chunk looks below itself, the one above) are cut
-        // separately: everything else then runs the loop without z-layer code.  Local plane = global plane - zoff.
-        a.zcut[0] = np[2][0] > 0 ? std::max(a.kl0, std::min(np[2][0] + 4 - zoff, a.kl1)) : a.kl0;
-        a.zcut[1] = np[2][1] > 0 ? std::min(a.kl1, std::max(a.zcut[0], d.Nz - np[2][1] - 2 - zoff)) : a.kl1;
-        const int len[3] = {a.zcut[0] - a.kl0, a.zcut[1] - a.zcut[0], a.kl1 - a.zcut[1]};
-        int nb[3];
-        for (int q = 0; q < 3; ++q) {
-            a.zchunk[q] = (q == 1 || chunk_pair > 0) ? a.chunk : std::max(1, len[q]);      // a face segment is one chunk unless told otherwise
-            nb[q] = (len[q] + a.zchunk[q] - 1) / a.zchunk[q];
-        }
-        a.znb[0] = nb[0]; a.znb[1] = nb[1];
-        a.nbz = nb[0] + nb[1] + nb[2];
         // tile order: as dealt (x tiles fastest, round-robin over the XCDs) -- measured at 1024^3 with CPML: 12.3 ms
         // against 12.7 with the x tiles of a row group kept on one XCD
         a.remap = remap == kRemapAuto ? 0 : remap;
-        const unsigned nblk = (unsigned)a.nbx * a.nby * a.nbz;
-        const size_t lds = ((size_t)6 + (size_t)3 * 2 * wpbp * 2) * TW * sizeof(T);
-        const size_t scr_need = pml ? (size_t)nblk * wpbp * 24 * TW : 0;
-        if (scr_need > pair_scr_elems) {
-            if (int rc = dalloc((void**)&pair_scr, scr_need * sizeof(T), 0)) return rc;    // the old piece stays with the engine
-            pair_scr_elems = scr_need;
+        const int lo = 1, hi = last_rank ? nzp : nzp - 1;         // the owned planes (on a slab: see fdtd3d_step_pairs)
+        const int cut = std::min(lo + kPairEdge, hi), cut2 = std::max(cut, hi - kPairEdge);
+        int rc = FDTD_OK;
+        if (part == FDTD3D_PART_ALL) rc = pair_launch(a, lo, hi, part, pml, s);
+        else if (part == FDTD3D_PART_EDGE) { rc = pair_launch(a, lo, cut, part, pml, s); if (!rc) rc = pair_launch(a, cut2, hi, part, pml, s); }
+        else rc = pair_launch(a, cut, cut2, part, pml, s);
+        if (rc) return rc;
+        if (part != FDTD3D_PART_INTERIOR) {
+            for (int c = 0; c < 3; ++c) {
+                std::swap(fld[c], alt[c]); std::swap(fld[6 + c], alt[6 + c]);
+                if (pml) for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) { std::swap(phE[c][ax][sd], phE2[c][ax][sd]); std::swap(phM[c][ax][sd], phM2[c][ax][sd]); }
+            }
+            ++flips;
         }
-        a.pair_scr = pair_scr;
-        auto go = [&](auto kern) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(nblk), dim3(kLanes * wpbp), lds, s, a);
-        };
-        timer.begin(3, s, 0);
-        if (pml) { if (d.has_mu) go(k3_pair<T, true, true, PV>); else go(k3_pair<T, false, true, PV>); }
-        else { if (d.has_mu) go(k3_pair<T, true, false, PV>); else go(k3_pair<T, false, false, PV>); }
-        timer.end(s);
-        FDTD_HIP(hipGetLastError());
-        for (int c = 0; c < 3; ++c) {
-            std::swap(fld[c], alt[c]); std::swap(fld[6 + c], alt[6 + c]);
-            if (pml) for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) { std::swap(phE[c][ax][sd], phE2[c][ax][sd]); std::swap(phM[c][ax][sd], phM2[c][ax][sd]); }
-        }
-        ++flips;
+        pair_phase = part == FDTD3D_PART_EDGE ? 1 : 0;
         return FDTD_OK;
     }
 
@@ -1456,6 +1487,12 @@ int fdtd3d_step_pairs(fdtd3d_handle h, int n0, int pairs, void* stream) {
         for (int q = 0; q < pairs; ++q)
             if (int rc = h->step_pair(n0 + 2 * q, (hipStream_t)stream)) return rc;
         return FDTD_OK;
+    });
+}
+int fdtd3d_pair_part(fdtd3d_handle h, int n, int part, void* stream) {
+    return entry(h, [&]() -> int {
+        if (h->probe_count() > 0) return fail(FDTD_ERR_STATE, "two-step launches cannot sample probes after the first of their steps");
+        return h->step_pair_part(n, part, (hipStream_t)stream);
     });
 }
 int fdtd3d_pair_info(fdtd3d_handle h, int out[4]) {

@@ -225,6 +225,10 @@ class Engine3D(_Common):
             shape["pair"] = pair
         return shape
 
+    def pair_part(self, n: int, part: int = PART_ALL, stream=None) -> None:
+        """Steps n, n+1 in one launch (PART_ALL) or as PART_EDGE then PART_INTERIOR (fdtd3d_pair_part)."""
+        _check(lib().fdtd3d_pair_part(self.h, C.c_int(n), C.c_int(part), _stream_handle(stream)), "fdtd3d_pair_part")
+
     def pair_shape(self, chunk: int = 0, rows: int = 0) -> None:
         _check(lib().fdtd3d_pair_shape(self.h, C.c_int(chunk), C.c_int(rows)), "fdtd3d_pair_shape")
 

@@ -211,8 +211,9 @@ class PairSlabStepper:
     answers for [z_lo, z_hi), and after every launch the two planes beyond each cut -- D, B and the x- and y-face
     CPML state of both families -- are overwritten with the neighbour's exact ones: planes z_hi-2, z_hi-1 go up,
     planes z_lo, z_lo+1 go down (each a contiguous device range per array).  One exchange per two steps instead of
-    two per step; nothing overlaps it yet (the whole launch has to finish before its edge planes exist).  An odd
-    step at the end is one launch of the one-step kernel followed by the same exchange.
+    two per step; the launch is cut in two (pair_part: the three planes at either end first, then the bulk) so that
+    the planes travel while the bulk is computed -- the neighbour's bulk launch neither reads the buffers they land in
+    nor writes those planes.  An odd step at the end is one launch of the one-step kernel followed by the same exchange.
 
     `engine` needs step_pairs(n, 1), fused(n, part), parity() and planes via `tensor_of(engine, id, k, count)`.
     """
@@ -220,10 +221,12 @@ class PairSlabStepper:
     def __init__(self, engine, rank: int, world: int, own: Tuple[int, int], ids: Sequence[int], tensor_of, group=None, stream=None):
         self.engine, self.rank, self.world, self.own, self.ids = engine, rank, world, own, list(ids)
         self.tensor_of, self.group, self.stream = tensor_of, group, stream
+        self.split = hasattr(engine, "pair_part")     # launch in parts so that the exchange overlaps the bulk
         self._x = {}                      # HaloExchange per set of current buffers
         self._singles = 0                 # one-step launches so far: they swap D and B but not the B-side CPML buffers
 
-    def _exchange(self) -> None:
+    def _post(self):
+        """Start the exchange of the planes beyond the cuts out of / into the buffers that are current now."""
         e = self.engine
         key = (e.parity(), self._singles & 1)
         if key not in self._x:
@@ -233,12 +236,22 @@ class PairSlabStepper:
             self._x[key] = HaloExchange(self.rank, self.world, t(hi - 2) if up else [], t(lo - 2) if down else [],
                                         t(lo) if down else [], t(hi) if up else [], self.group)
         x = self._x[key]
-        reqs = x.start_up() + x.start_down()
-        HaloExchange.wait(reqs)
+        return x.start_up() + x.start_down()
+
+    def _exchange(self) -> None:
+        HaloExchange.wait(self._post())
 
     def pair(self, n: int) -> None:
-        self.engine.step_pairs(n, 1, self.stream)
-        self._exchange()
+        e = self.engine
+        if not self.split:
+            e.step_pairs(n, 1, self.stream)
+            self._exchange()
+            return
+        # the planes next to the cuts first (the buffers change roles with this launch), on their way while the bulk runs
+        e.pair_part(n, PART_EDGE, self.stream)
+        reqs = self._post()
+        e.pair_part(n, PART_INTERIOR, self.stream)
+        HaloExchange.wait(reqs)
 
     def single(self, n: int) -> None:
         self.engine.fused(n, PART_ALL, self.stream)

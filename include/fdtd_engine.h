@@ -156,6 +156,11 @@ int fdtd3d_pair_shape(fdtd3d_handle h, int chunk, int rows);
  * component, or an x- or y-face CPML array) in the buffers that are current now -- fetch again after every
  * step, the buffers change roles.  Pointer arithmetic only. */
 int fdtd3d_planes(fdtd3d_handle h, int id, int k, int count, void** p, size_t* bytes);
+/* Steps n and n+1 in parts, so that a slab driver can have the planes next to its cuts on their way while
+ * the bulk is computed: FDTD3D_PART_EDGE = the three lowest and the three highest owned planes (two small
+ * launches; the buffers change roles here, as with fdtd3d_fused, so fdtd3d_planes already refers to the new
+ * values), then FDTD3D_PART_INTERIOR = the rest.  FDTD3D_PART_ALL = fdtd3d_step_pairs(h, n, 1, stream). */
+int fdtd3d_pair_part(fdtd3d_handle h, int n, int part, void* stream);
 /* out = { 1 if fdtd3d_step takes its steps two per launch on this engine, planes per workgroup,
  *         waves per workgroup, elements per lane } of the two-step kernel. */
 int fdtd3d_pair_info(fdtd3d_handle h, int out[4]);

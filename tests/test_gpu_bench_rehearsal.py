@@ -64,8 +64,8 @@ def _check_multi_gpu_block(line, ranks, mode, backend):
         assert rec["layers"][1] > rec["layers"][0]
         ms, n, idle = rec["launch_ms_per_step"], rec["launches_per_step"], rec["stream_idle_ms_per_step_before"]
         if mode == "fused" and "one host thread" not in backend:
-            # 7 timed steps: three two-step launches and one launch of the one-step kernel
-            want = {"pair_all", "fused_all"}
+            # 7 timed steps: three two-step launches (each as edge planes + bulk) and one launch of the one-step kernel
+            want = {"pair_edge", "pair_interior", "fused_all"}
             assert rec["stepper"] == "PairSlabStepper"
             assert rec["stored_layers"][0] <= rec["layers"][0] and rec["stored_layers"][1] >= rec["layers"][1]
         elif mode in ("fused", "fused-single"):
@@ -74,7 +74,7 @@ def _check_multi_gpu_block(line, ranks, mode, backend):
             want = {"half_e_interior", "half_e_edge", "half_h_interior", "half_h_edge"}
         assert want <= set(ms), (r, sorted(ms))
         # (per STEP: a two-step launch counts half)
-        assert all(ms[k] > 0 and (n[k] >= 1 or (n[k] > 0 and "pair_all" in want)) for k in want)
+        assert all(ms[k] > 0 and (n[k] >= 1 or (n[k] > 0 and "pair_edge" in want)) for k in want)
         assert all(v >= 0 for v in idle.values())
         assert abs(sum(ms.values()) - rec["kernel_ms_per_step"]) < 1e-6 * max(1.0, rec["kernel_ms_per_step"]) or not mode.startswith("fused")
         assert rec["first_to_last_launch_ms_per_step"] >= sum(ms.values()) * 0.999

@@ -283,14 +283,41 @@ class PairLine:
         self.cur ^= 1
 
 
-def _pair_worker(rank, world, port, Nz, runs, out):
+class SplitPairLine(PairLine):
+    """The same with the two-step launch in two parts (fdtd3d_pair_part): the three planes at either end first -- the
+    buffer sets change roles there -- then the rest, so that the stepper can post the exchange in between."""
+
+    def pair_part(self, n, part, stream=None):
+        owned = list(self._owned())
+        edge = [kl for kl in owned if kl < owned[0] + 3 or kl > owned[-1] - 3]
+        if part == slab.PART_EDGE:
+            E, H = self.fields[self.cur]
+            A = self.aux[self.cur_aux]
+            E1, H1, A1 = self._one_step(E, H, A, n)
+            self._res = self._one_step(E1, H1, A1, n + 1)
+            for arr in self.fields[self.cur ^ 1] + [self.aux[self.cur_aux ^ 1]]:
+                arr.fill_(float("nan"))
+            self.cur ^= 1
+            self.cur_aux ^= 1
+            todo = edge
+        else:
+            assert part == slab.PART_INTERIOR
+            todo = [kl for kl in owned if kl not in edge]
+        nE, nH = self.fields[self.cur]
+        nA = self.aux[self.cur_aux]
+        for kl in todo:
+            nE[kl], nH[kl], nA[kl] = self._res[0][kl], self._res[1][kl], self._res[2][kl]
+
+
+def _pair_worker(rank, world, port, Nz, runs, out, split=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     parts = slab.partition(Nz, world)
     own = parts[rank]
     s_lo, s_hi = slab.pair_slab_range(own[0], own[1], Nz)
-    eng = PairLine(Nz, s_lo, s_hi, kJ=3)
+    eng = (SplitPairLine if split else PairLine)(Nz, s_lo, s_hi, kJ=3)
     st = slab.PairSlabStepper(eng, rank, world, own, [0, 1, 2], lambda e, id_, k, count: e.planes(id_, k, count))
+    assert st.split == split
     st.prime()
     n = 0
     for count in runs:
@@ -311,8 +338,9 @@ def _pair_worker(rank, world, port, Nz, runs, out):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("world,runs", [(2, [8, 5, 4]), (3, [3, 6, 7]), (2, [1, 1, 2])])
-def test_pair_exchange_reproduces_single_rank(tmp_path, world, runs):
+def test_pair_exchange_reproduces_single_rank(tmp_path, world, runs, split):
     """Two steps per launch on overlapping slabs: pairs, odd steps in between (the buffer sets then change roles
     unevenly), several ranks -- equal to one rank stepping the whole line one step at a time."""
     Nz = 29
@@ -323,7 +351,7 @@ def test_pair_exchange_reproduces_single_rank(tmp_path, world, runs):
         ref.half_h(slab.PART_ALL)
         aux = 0.5 * aux + ref.E
     out = str(tmp_path / "pslab")
-    mp.spawn(_pair_worker, args=(world, _free_port(), Nz, runs, out), nprocs=world, join=True)
+    mp.spawn(_pair_worker, args=(world, _free_port(), Nz, runs, out, split), nprocs=world, join=True)
     e, h, a = (np.load(out + f"_{c}.npy") for c in "eha")
     assert np.array_equal(e, ref.E[1:Nz + 2].numpy())
     assert np.array_equal(h, ref.H[1:Nz + 1].numpy())

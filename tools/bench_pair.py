@@ -20,6 +20,7 @@ ap.add_argument("--chunk", type=int, default=0)
 ap.add_argument("--rows", type=int, default=0)
 ap.add_argument("--only", default="")
 ap.add_argument("--remap", type=int, default=-1)
+ap.add_argument("--split", type=int, default=0, help="two-step launches as edge planes + bulk (what the slab stepper does)")
 ap.add_argument("--check", type=int, default=1)
 ap.add_argument("--npml", default="0", help="layers on every face, or six numbers x-,x+,y-,y+,z-,z+")
 a = ap.parse_args()
@@ -59,7 +60,11 @@ for kind in ("single", "pair"):
         eng.pair_shape(a.chunk, a.rows)
         if a.remap >= 0:
             eng.tune(0, a.remap, 0)
-        el = timed(eng, lambda n0, pairs: eng.step_pairs(n0, pairs))
+        def split_pairs(n0, pairs):
+            for q in range(pairs):
+                eng.pair_part(n0 + 2 * q, E.PART_EDGE)
+                eng.pair_part(n0 + 2 * q, E.PART_INTERIOR)
+        el = timed(eng, split_pairs if a.split else (lambda n0, pairs: eng.step_pairs(n0, pairs)))
     else:
         el = timed(eng, lambda n0, pairs: eng.step(n0, 2 * pairs))
     out[kind] = {"ms_per_step": el * 1e3, "Gcell_per_s": cells / el / 1e9, "gap_GiB": eng.spread_gap_gib()}
