@@ -1095,6 +1095,7 @@ struct Engine3 : fdtd3d_engine {
         a.Nx = d.Nx; a.Ny = d.Ny; a.Nz = d.Nz; a.px = px; a.ny1 = ny1; a.nzp = nzp; a.zoff = zoff;
         for (int ax = 0; ax < 3; ++ax) for (int s = 0; s < 2; ++s) a.np[ax][s] = np[ax][s];
         a.xwn = xwn; a.xwp = xwp; a.xp0 = xp0;
+        a.wrap_l = 0; a.wrap_r0 = 0;
         a.kJ = d.k_Jx; a.src_on = 0; a.jx = (T)0;
         a.dt = (T)d.dt; a.dtd[0] = (T)(d.dt / d.dx); a.dtd[1] = (T)(d.dt / d.dy); a.dtd[2] = (T)(d.dt / d.dz); a.mu0 = (T)d.mu0;
         a.nbx = px / (kLanes * V); a.nby = (ny1 + wpb - 1) / wpb; a.wpb = wpb;
@@ -1260,11 +1261,28 @@ struct Engine3 : fdtd3d_engine {
         return (size_t)d.Nx * d.Ny * d.Nz >= kPairMinCells;
     }
     static constexpr size_t kPairMinCells = (size_t)384 * 384 * 384;
-    int pair_nbx() const {
-        constexpr int TW = kLanes * (V / 2), XS = TW - 4;
+    // x tiles of the two-step kernel: in a row, each overlapping the next by four columns; or, when both x faces carry
+    // CPML layers and both strips fit one wave, tile 0 takes both ends of the row (its first `wrap_l` lanes the left
+    // end, the others the columns from `wrap_r0` on, each part reaching four columns beyond its strip) and the other
+    // tiles follow the left part: one x tile in nine instead of two then runs the x-strip loop (FDTD_PAIR_WRAP=0: never)
+    struct PairTiles { int nbx, wrap_l, wrap_r0; };
+    PairTiles pair_tiles() const {
+        constexpr int PV = V / 2, TW = kLanes * PV, XS = TW - 4;
         const int cover = std::min(d.Nx + 1, px);            // columns that hold anything
-        return cover > TW - 2 ? (cover - (TW - 2) + XS - 1) / XS + 1 : 1;
+        PairTiles t{cover > TW - 2 ? (cover - (TW - 2) + XS - 1) / XS + 1 : 1, 0, 0};
+        const char* e = getenv("FDTD_PAIR_WRAP");
+        if (t.nbx > 1 && np[0][0] > 0 && np[0][1] > 0 && !(e && atoi(e) == 0)) {
+            const int r0 = xp0 - 4;                          // first column of the right part (xp0 is a multiple of 4)
+            const int rend = std::min(px, round_up(cover + 2, 4));      // the right part ends in the padding, or at the wall
+            const int nr = (rend - r0) / PV, nl = kLanes - nr;
+            if (r0 >= 0 && nl * PV >= xwn + 4 && nl * PV <= r0) {
+                const int from = nl * PV - 2, to = r0 + 2;   // what the tiles after tile 0 own
+                t = PairTiles{1 + (to > from ? (to - from + XS - 1) / XS : 0), nl, r0};
+            }
+        }
+        return t;
     }
+    int pair_nbx() const { return pair_tiles().nbx; }
     // planes per workgroup: long chunks amortise the three extra iterations of a chunk, but the launch should
     // still have a few workgroups per CU
     int pair_chunk() const {
@@ -1348,7 +1366,8 @@ struct Engine3 : fdtd3d_engine {
                 std::swap(a.D[c], a.Dn[c]); std::swap(a.B[c], a.Bn[c]);
                 for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) { std::swap(a.phE[c][ax][sd], a.phEn[c][ax][sd]); std::swap(a.phM[c][ax][sd], a.phMn[c][ax][sd]); }
             }
-        a.nbx = pair_nbx();
+        const PairTiles tiles = pair_tiles();
+        a.nbx = tiles.nbx; a.wrap_l = tiles.wrap_l; a.wrap_r0 = tiles.wrap_r0;
         a.wpb = wpbp;
         a.nby = (ny1 + (wpbp - 3) - 1) / (wpbp - 3);
         a.chunk = pair_chunk();

@@ -59,6 +59,9 @@ struct K3 {
     T* phMn[3][3][2];  // the B-side CPML state it writes (ping-pong, like phEn)
     int zcut[2], zchunk[3], znb[2];   // the two-step kernel's three plane segments (kernels3d_pair.hpp)
     T* pair_scr;       // CPML state between the two steps of a launch: [workgroup][wave][2 planes][12 terms][columns of a wave]
+    // two-step kernel: x tile 0 may hold BOTH ends of a row (lanes [0, wrap_l) the first columns, the other lanes the
+    // columns from wrap_r0 on), so that one x tile instead of two meets the x-face CPML strips; 0 = tiles in a row
+    int wrap_l, wrap_r0;
 };
 
 template <typename T, int V>

@@ -116,14 +116,22 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
     const int by = bid % a.nby;
     const int bz = bid / a.nby;
     const int px = a.px, Ny = a.Ny, Nz = a.Nz;
-    const int c0 = bx * XS;
-    const bool live = c0 + (int)lo < px;
-    // lanes past the end of the row (last x tile only) read the row's last pack instead: whatever they compute is
-    // neither stored nor seen by a live lane (the column right of the last stored one is the wall: zero, below)
-    const unsigned lc = live ? lo : (unsigned)(px - V - c0);
-    const int i0 = c0 + (int)lc;
-    const bool own_x = live && (bx == 0 || i0 >= c0 + 2) && i0 + V <= c0 + TW - 2;
-    const bool wall_r = c0 + (int)lo + V >= px;
+    // x tiles: in a row (tile bx starts at column bx * XS), or -- wrap_l > 0 -- tile 0 holds both ends of the row: its
+    // lanes [0, wrap_l) the first columns, the others the columns from wrap_r0 on; the tiles after it follow the left
+    // part.  The seam inside tile 0 is a tile boundary like any other: two columns either side of it are computed, not
+    // stored (the left part's last two are the next tile's, the right part's first two the last tile's).  The host makes
+    // both parts reach two columns beyond the CPML strips, so that no other tile meets them.
+    const bool wrap = a.wrap_l > 0 && bx == 0;
+    const int c0 = wrap ? 0 : (a.wrap_l > 0 ? a.wrap_l * V - 4 + (bx - 1) * XS : bx * XS);      // base of this tile's addresses
+    const int col = wrap ? ((int)lane < a.wrap_l ? (int)lo : a.wrap_r0 + ((int)lane - a.wrap_l) * V) : c0 + (int)lo;
+    const bool live = col < px;
+    // lanes past the end of the row read the row's last pack instead: whatever they compute is neither stored nor
+    // seen by a live lane (the column right of the last stored one is the wall: zero, below)
+    const int i0 = live ? col : px - V;
+    const unsigned lc = (unsigned)(i0 - c0);             // this lane's columns relative to the tile's base
+    const bool own_x = live && (wrap ? ((int)lane < a.wrap_l ? col + V <= a.wrap_l * V - 2 : col >= a.wrap_r0 + 2)
+                                     : ((c0 == 0 || col >= c0 + 2) && col + V <= c0 + TW - 2 && (a.wrap_l == 0 || col < a.wrap_r0 + 2)));
+    const bool wall_r = wrap ? lane == kLanes - 1 : col + V >= px;      // (the right part ends in the zero padding, or at the wall)
     const bool first = i0 == 0;
     const int jr = by * (W - 3) - 1 + w;
     const bool row_ok = jr >= 0 && jr < a.ny1;
@@ -143,7 +151,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
     bool near_x = false, near_y = false, near_z = false;
     if constexpr (PML) {
         const int r0 = by * (W - 3) - 1;
-        near_x = (a.np[0][0] > 0 && c0 < a.xwn) || (a.np[0][1] > 0 && c0 + TW > a.xp0);
+        near_x = a.wrap_l > 0 ? wrap : ((a.np[0][0] > 0 && c0 < a.xwn) || (a.np[0][1] > 0 && c0 + TW > a.xp0));
         near_y = (a.np[1][0] > 0 && r0 <= a.np[1][0]) || (a.np[1][1] > 0 && r0 + W - 1 >= Ny - a.np[1][1]);
         const int g_lo = kb - 4 + a.zoff + 1, g_hi = ke + 1 + a.zoff;      // global planes the stages of this chunk touch
         near_z = (a.np[2][0] > 0 && g_lo <= a.np[2][0]) || (a.np[2][1] > 0 && g_hi >= Nz - a.np[2][1]);
@@ -188,7 +196,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
         auto mid_of = [&](int mpar, int term) -> T* { return ap->pair_scr + mid_off + (size_t)(mpar * 12 + term) * TW; };
 
         auto h_of = [&](const P& b, const P& m) -> P { return MU ? divide<T, V>(b, m) : divide<T, V>(b, a.mu0); };
-        auto left_of_tile = [&](T shifted) -> T { return (lane == 0 && bx == 0) ? (T)0 : shifted; };
+        auto left_of_tile = [&](T shifted) -> T { return (lane == 0 && c0 == 0) ? (T)0 : shifted; };
         auto right_of_tile = [&](T shifted) -> T { return wall_r ? (T)0 : shifted; };
 
         // ---- the two kinds of term.  step 0: state from the old buffers into `mid`; step 1: from `mid` into the new buffers.
@@ -211,7 +219,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
                 if (!have_pre) ph = step == 0 ? ldg<T, V>(src[side] + off, lc) : ldg<T, V>(m, lo);
                 pair_cpml_u<SIGN, T, V>(d, curl, skip0, side != 0, face + kb3 * kMaxLayers + l, dt, ph);
                 if (step == 0) stg<T, V>(m, lo, ph);
-                else if (st) stg<T, V>(dst[side] + off, lo, ph);
+                else if (st) stg<T, V>(dst[side] + off, lc, ph);
             }
         };
         // A wave waits for memory once per stage, not once per term: the state of ONE family of layers -- the x strips if
@@ -433,9 +441,9 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
                 update_d(d2, h1[0], h1[1], h1[2], h1_km2[0], h1_km2[1], hx_jm1, hz_jm1, hy_l, hz_l, kl - 1, km, 1, par ^ 1, st, famC, preC0, preC1);
                 if (st) {
                     const size_t rs = ro - sz * (size_t)(klc - (kl - 1));
-                    stg_nt<T, V>(ap->Dn[0] + rs, lo, d2[0]);
-                    if (row_lt) stg_nt<T, V>(ap->Dn[1] + rs, lo, d2[1]);
-                    if (km >= 0 && km < Nz) stg_nt<T, V>(ap->Dn[2] + rs, lo, d2[2]);
+                    stg_nt<T, V>(ap->Dn[0] + rs, lc, d2[0]);
+                    if (row_lt) stg_nt<T, V>(ap->Dn[1] + rs, lc, d2[1]);
+                    if (km >= 0 && km < Nz) stg_nt<T, V>(ap->Dn[2] + rs, lc, d2[2]);
                 }
 #pragma unroll
                 for (int c = 0; c < 3; ++c) e2[c] = divide<T, V>(d2[c], ep_km[c]);
@@ -453,9 +461,9 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
                 update_b(b2, e2_km2, e2, ex_jp, ez_jp, ey_r, ez_r, kl - 2, km2, 1, par, own, famD, preD0, preD1);
                 if (own) {
                     const size_t rs = ro - sz * (size_t)(klc - (kl - 2));
-                    if (row_lt && bl_lt) stg_nt<T, V>(ap->Bn[0] + rs, lo, b2[0]);
-                    if (bl_lt) stg_nt<T, V>(ap->Bn[1] + rs, lo, b2[1]);
-                    if (row_lt) stg_nt<T, V>(ap->Bn[2] + rs, lo, b2[2]);
+                    if (row_lt && bl_lt) stg_nt<T, V>(ap->Bn[0] + rs, lc, b2[0]);
+                    if (bl_lt) stg_nt<T, V>(ap->Bn[1] + rs, lc, b2[1]);
+                    if (row_lt) stg_nt<T, V>(ap->Bn[2] + rs, lc, b2[2]);
                 }
             }
 

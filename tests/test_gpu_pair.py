@@ -77,10 +77,14 @@ def test_pairs_equal_reference_3d(name, prec, rows, chunk):
     (64, (140, 6, 19), (62, 20, 0, 3, 4, 4)),     # fp64 tiles own 60 columns: boundary inside the low strip
     (64, (12, 33, 9), (4, 4, 4, 4, 4, 4)),
     (32, (64, 12, 40), (2, 2, 2, 2, 18, 19)),     # nearly every plane in a z layer
+    (32, (256, 7, 9), (20, 20, 2, 2, 2, 2)),      # Nx = row pitch: the right end of a row ends at the wall, not in padding
+    (64, (140, 6, 19), (10, 8, 0, 3, 4, 4)),      # fp64, both strips in x tile 0, two tiles after it
 ])
 @pytest.mark.parametrize("has_mu", [False, True])
 @pytest.mark.parametrize("rows,chunk", [(16, 48), (6, 2), (11, 3)])
-def test_pairs_with_cpml_equal_twin_ragged(prec, N, npml, has_mu, rows, chunk):
+@pytest.mark.parametrize("wrap", ["1", "0"])      # x tile 0 holding both ends of a row (where both strips fit it), or tiles in a row
+def test_pairs_with_cpml_equal_twin_ragged(prec, N, npml, has_mu, rows, chunk, wrap, monkeypatch):
+    monkeypatch.setenv("FDTD_PAIR_WRAP", wrap)
     K = po.consts()
     d = (5e-8, 6e-8, 7e-8)
     dt = 5e-8 / (2 * K["c0"])
