@@ -264,6 +264,8 @@ struct fdtd3d_engine {
     virtual int probe_read(double* out, size_t cap, int* n_samples, int* n_probes) = 0;
     virtual int probe_reset(int drop_probes) = 0;
     virtual int probe_count() = 0;
+    virtual int pair_peek_probes(int n, hipStream_t s) = 0;
+    virtual void probe_unrecord() = 0;
     virtual int halo(int which, int comp, void** p, size_t* bytes, int at_parity) = 0;
     virtual int reduce(int id, double* sumsq, uint64_t* checksum, hipStream_t s) = 0;
     virtual int reduce_static(const int* ids, int n_ids, double* sumsq, uint64_t* checksum, hipStream_t s) = 0;
@@ -344,6 +346,7 @@ struct Engine3 : fdtd3d_engine {
     // ---- probe time series ----------------------------------------------------------------
     ProbeLog<T> probes;
     int probe_count() override { return (int)probes.specs.size(); }
+    void probe_unrecord() override { if (probes.rows > 0) --probes.rows; }      // drops the newest row
     int probe_add(int id, int i, int j, int k) override {
         Map m;
         if (id < 0 || id >= 18 || !make_map(id, m)) return fail(FDTD_ERR_ARG, "probe_add: %d is not a field array", id);
@@ -1095,7 +1098,7 @@ struct Engine3 : fdtd3d_engine {
         a.Nx = d.Nx; a.Ny = d.Ny; a.Nz = d.Nz; a.px = px; a.ny1 = ny1; a.nzp = nzp; a.zoff = zoff;
         for (int ax = 0; ax < 3; ++ax) for (int s = 0; s < 2; ++s) a.np[ax][s] = np[ax][s];
         a.xwn = xwn; a.xwp = xwp; a.xp0 = xp0;
-        a.wrap_l = 0; a.wrap_r0 = 0;
+        a.wrap_l = 0; a.wrap_r0 = 0; a.peek = 0;
         a.kJ = d.k_Jx; a.src_on = 0; a.jx = (T)0;
         a.dt = (T)d.dt; a.dtd[0] = (T)(d.dt / d.dx); a.dtd[1] = (T)(d.dt / d.dy); a.dtd[2] = (T)(d.dt / d.dz); a.mu0 = (T)d.mu0;
         a.nbx = px / (kLanes * V); a.nby = (ny1 + wpb - 1) / wpb; a.wpb = wpb;
@@ -1190,6 +1193,65 @@ struct Engine3 : fdtd3d_engine {
         if (phase == 1) return fail(FDTD_ERR_STATE, "fused: the part holding the top layer (TOP or INTERIOR) has not been launched");
         return last_rank ? FDTD_OK : half_h(FDTD3D_PART_EDGE, s);
     }
+    // arguments of a one-step fused launch for step n: reads the current buffers, writes the other set (`swapped`: the
+    // roles were already exchanged when the step's first part was launched)
+    K3<T> fused_args(int n, bool swapped) {
+        K3<T> a = args();
+        a.src_on = (n >= 0 && n < (int)wf.size()) ? 1 : 0;
+        a.jx = a.src_on ? a.dt * wf[n] : (T)0;
+        for (int c = 0; c < 3; ++c) {
+            a.Dn[c] = alt[c]; a.Bn[c] = alt[6 + c];
+            for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) a.phEn[c][ax][sd] = phE2[c][ax][sd];
+        }
+        if (swapped)
+            for (int c = 0; c < 3; ++c) {
+                std::swap(a.D[c], a.Dn[c]); std::swap(a.B[c], a.Bn[c]);
+                for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) std::swap(a.phE[c][ax][sd], a.phEn[c][ax][sd]);
+            }
+        a.wpb = wpbf;
+        // tile order of the fused kernel: the x tiles of one row group share an XCD (their edge columns meet
+        // in its L2), successive row groups go round the XCDs, so that all XCDs stream from the same planes
+        if (remap == kRemapAuto) a.remap = std::max(2, px / (kLanes * fvec));
+        a.nby = (ny1 + (wpbf - 1) - 1) / (wpbf - 1);
+        a.kl_stop = last_rank ? nzp : nzp - 1; a.copy_top = last_rank ? 0 : 1;
+        return a;
+    }
+    int fused_go(K3<T>& a, int kl0, int kl1, int part, hipStream_t s) {
+        a.kl0 = kl0; a.kl1 = kl1;
+        a.nbz = (a.kl1 - a.kl0 + a.chunk - 1) / a.chunk;
+        if (kl1 > kl0) {
+            timer.begin(2, s, part);
+            if (fvec == V) launch_fused<V>(a, s); else launch_fused<V / 2>(a, s);
+            timer.end(s);
+            FDTD_HIP(hipGetLastError());
+        }
+        return FDTD_OK;
+    }
+    // Probes on a two-step launch: the values after the FIRST of the two steps never reach memory, so they are formed
+    // here, before the launch, by one-plane launches of the one-step kernel over the planes that hold probes.  These
+    // read the current buffers and write the other set -- which the two-step launch then overwrites -- and leave the
+    // B-side CPML state, which the one-step kernel keeps in place, untouched (`peek`).  The row is sampled from the
+    // other set; the second step's row is an ordinary probe_record() after the launch.
+    int pair_peek_probes(int n, hipStream_t s) override {
+        if (probes.specs.empty()) return FDTD_OK;
+        if (!fused || phase != 0 || pair_phase != 0) return fail(FDTD_ERR_STATE, "probes before a two-step launch: engine is in the middle of a step");
+        std::vector<int> planes;
+        for (const ProbeSpec& sp : probes.specs) {
+            const int kl = (int)(sp.off / (long long)plane);
+            if (std::find(planes.begin(), planes.end(), kl) == planes.end()) planes.push_back(kl);
+        }
+        K3<T> a = fused_args(n, false);
+        a.peek = 1;
+        for (int kl : planes) if (int rc = fused_go(a, kl, kl + 1, FDTD3D_PART_ALL, s)) return rc;
+        T* row = nullptr;
+        if (int rc = probes.next_row(&row, (int)wf.size() + 8)) return rc;
+        PtrTable<T, 18> t;
+        for (int q = 0; q < 18; ++q) t.p[q] = fld[q];
+        for (int c = 0; c < 3; ++c) { t.p[c] = alt[c]; t.p[6 + c] = alt[6 + c]; }
+        hipLaunchKernelGGL((k_probe<T, 18>), dim3(1), dim3(kMaxProbes), 0, s, t, probes.specs_d, (int)probes.specs.size(), row);
+        FDTD_HIP(hipGetLastError());
+        return FDTD_OK;
+    }
     int fused_part(int n, int part, hipStream_t s) override {
         if (!fused) return fail(FDTD_ERR_STATE, "fused stepping needs an engine created with FDTD3D_MODE_FUSED");
         // EDGE only has to produce layer z_lo early, TOP only the top layer: these launches have too few
@@ -1206,32 +1268,8 @@ struct Engine3 : fdtd3d_engine {
         if (first_of_step ? phase != 0 : (part == FDTD3D_PART_TOP ? phase != 1 : phase == 0))
             return fail(FDTD_ERR_STATE, "fused: a step is ALL, or EDGE [TOP] INTERIOR in this order");
         const bool mid_step = !first_of_step;
-        K3<T> a = args();
-        a.src_on = (n >= 0 && n < (int)wf.size()) ? 1 : 0;
-        a.jx = a.src_on ? a.dt * wf[n] : (T)0;
-        for (int c = 0; c < 3; ++c) {
-            a.Dn[c] = alt[c]; a.Bn[c] = alt[6 + c];
-            for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) a.phEn[c][ax][sd] = phE2[c][ax][sd];
-        }
-        if (mid_step)      // the roles were exchanged when EDGE was launched
-            for (int c = 0; c < 3; ++c) {
-                std::swap(a.D[c], a.Dn[c]); std::swap(a.B[c], a.Bn[c]);
-                for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) std::swap(a.phE[c][ax][sd], a.phEn[c][ax][sd]);
-            }
-        a.wpb = wpbf;
-        // tile order of the fused kernel: the x tiles of one row group share an XCD (their edge columns meet
-        // in its L2), successive row groups go round the XCDs, so that all XCDs stream from the same planes
-        if (remap == kRemapAuto) a.remap = std::max(2, px / (kLanes * fvec));
-        a.nby = (ny1 + (wpbf - 1) - 1) / (wpbf - 1);
-        a.kl0 = kl0; a.kl1 = kl1;
-        a.kl_stop = hi; a.copy_top = last_rank ? 0 : 1;
-        a.nbz = (a.kl1 - a.kl0 + a.chunk - 1) / a.chunk;
-        if (kl1 > kl0) {
-            timer.begin(2, s, part);
-            if (fvec == V) launch_fused<V>(a, s); else launch_fused<V / 2>(a, s);
-            timer.end(s);
-            FDTD_HIP(hipGetLastError());
-        }
+        K3<T> a = fused_args(n, mid_step);
+        if (int rc = fused_go(a, kl0, kl1, part, s)) return rc;
         if (first_of_step) {
             for (int c = 0; c < 3; ++c) {
                 std::swap(fld[c], alt[c]); std::swap(fld[6 + c], alt[6 + c]);
@@ -1483,14 +1521,21 @@ int fdtd3d_fill_array(fdtd3d_handle h, int id, uint64_t seed, double lo, double 
 int fdtd3d_step(fdtd3d_handle h, int n0, int count, void* stream) {
     return entry(h, [&]() -> int {
         if (h->d.z_lo != 0 || h->d.z_hi != h->d.Nz) return fail(FDTD_ERR_STATE, "fdtd3d_step needs the whole grid on this device; slab drivers use fdtd3d_half_e / fdtd3d_half_h or fdtd3d_fused");
-        const bool pairs = h->pair_auto() && h->probe_count() == 0;      // a probe is sampled after every single step
+        const bool pairs = h->pair_auto();
+        const bool probed = h->probe_count() > 0;        // a probe is sampled after every single step: see pair_peek_probes
         for (int n = n0; n < n0 + count;) {
             if (pairs && n + 2 <= n0 + count && h->pair_auto()) {
+                if (probed) if (int rc = h->pair_peek_probes(n, (hipStream_t)stream)) return rc;
                 const int rc = h->step_pair(n, (hipStream_t)stream);
-                if (rc == FDTD_OK) { n += 2; continue; }
-                // device memory for the second B-side CPML buffers or the scratch ran out: nothing has been launched,
-                // the one-step kernel needs neither
+                if (rc == FDTD_OK) {
+                    if (int rc2 = h->probe_record((hipStream_t)stream)) return rc2;
+                    n += 2;
+                    continue;
+                }
+                // device memory for the second B-side CPML buffers or the scratch ran out: the two-step kernel has not
+                // been launched, the one-step kernel needs neither (and samples step n again)
                 if (rc != FDTD_ERR_HIP) return rc;
+                if (probed) h->probe_unrecord();
                 h->pair_give_up();
             }
             if (int rc = h->step(n, (hipStream_t)stream)) return rc;
@@ -1502,9 +1547,14 @@ int fdtd3d_step(fdtd3d_handle h, int n0, int count, void* stream) {
 }
 int fdtd3d_step_pairs(fdtd3d_handle h, int n0, int pairs, void* stream) {
     return entry(h, [&]() -> int {
-        if (h->probe_count() > 0) return fail(FDTD_ERR_STATE, "two-step launches cannot sample probes after the first of their steps");
-        for (int q = 0; q < pairs; ++q)
-            if (int rc = h->step_pair(n0 + 2 * q, (hipStream_t)stream)) return rc;
+        const bool probed = h->probe_count() > 0;
+        if (probed && (h->d.z_lo != 0 || h->d.z_hi != h->d.Nz))
+            return fail(FDTD_ERR_STATE, "two-step launches on a slab cannot sample probes after the first of their steps");
+        for (int q = 0; q < pairs; ++q) {
+            if (probed) if (int rc = h->pair_peek_probes(n0 + 2 * q, (hipStream_t)stream)) return rc;
+            if (int rc = h->step_pair(n0 + 2 * q, (hipStream_t)stream)) { if (probed) h->probe_unrecord(); return rc; }
+            if (int rc = h->probe_record((hipStream_t)stream)) return rc;
+        }
         return FDTD_OK;
     });
 }

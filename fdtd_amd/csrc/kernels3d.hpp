@@ -62,6 +62,7 @@ struct K3 {
     // two-step kernel: x tile 0 may hold BOTH ends of a row (lanes [0, wrap_l) the first columns, the other lanes the
     // columns from wrap_r0 on), so that one x tile instead of two meets the x-face CPML strips; 0 = tiles in a row
     int wrap_l, wrap_r0;
+    int peek;          // one-step fused kernel: leave the B-side CPML state (updated in place) as it is -- a launch whose results are only sampled
 };
 
 template <typename T, int V>

@@ -258,6 +258,7 @@ __global__ void __launch_bounds__(kLanes * MAXW) __attribute__((amdgpu_waves_per
     const T* face_y = a.tab + (size_t)(1 * 2) * 6 * kMaxLayers;
     const T* face_z = a.tab + (size_t)(2 * 2) * 6 * kMaxLayers;
     const bool row_lt = j < Ny, row_in = j >= 1 && j < Ny;
+    const bool mstore = a.peek == 0;      // (a launch whose results are only sampled leaves the in-place B-side CPML state alone)
 
     size_t ro = ((size_t)klb * a.ny1 + j) * px + c0;     // uniform offset of the wave's row segment in a field array
     P hx_km = zero_pack<T, V>(), hy_km = zero_pack<T, V>();
@@ -448,23 +449,23 @@ __global__ void __launch_bounds__(kLanes * MAXW) __attribute__((amdgpu_waves_per
             const size_t py0 = ((size_t)klm * a.np[1][0] + lyh) * px + c0, py1 = ((size_t)klm * a.np[1][1] + lyh) * px + c0;
             if (row_lt && bl_lt) {
                 P b = bo_km[0];
-                term_u2<+1, T, V>(b, diff<T, V>(en[1], en_km[1]), first, zkh, lkh, face_z, 3, a.dtd[2], a.dt, ap->phM[0][2], ap->phM[0][2], pz, pz, lo, true);
-                term_u2<-1, T, V>(b, diff<T, V>(ez_jp, en_km[2]), first, zyh, lyh, face_y, 3, a.dtd[1], a.dt, ap->phM[0][1], ap->phM[0][1], py0, py1, lo, true);
+                term_u2<+1, T, V>(b, diff<T, V>(en[1], en_km[1]), first, zkh, lkh, face_z, 3, a.dtd[2], a.dt, ap->phM[0][2], ap->phM[0][2], pz, pz, lo, mstore);
+                term_u2<-1, T, V>(b, diff<T, V>(ez_jp, en_km[2]), first, zyh, lyh, face_y, 3, a.dtd[1], a.dt, ap->phM[0][1], ap->phM[0][1], py0, py1, lo, mstore);
                 stg_nt<T, V>(ap->Bn[0] + rb, lo, b);
             }
             if (bl_lt) {
                 P b = bo_km[1];
                 if (row_in) {
-                    term_x3<+1, T, V>(b, diff_fwd_x<T, V>(en_km[2], ez_r), xs + 3 * TW, TW, pmy, a.dt, in_n, in_p, ap->phM[1][0], pxn, pxp, lo, true);
-                    term_u2<-1, T, V>(b, diff<T, V>(en[0], en_km[0]), false, zkh, lkh, face_z, 3, a.dtd[2], a.dt, ap->phM[1][2], ap->phM[1][2], pz, pz, lo, true);
+                    term_x3<+1, T, V>(b, diff_fwd_x<T, V>(en_km[2], ez_r), xs + 3 * TW, TW, pmy, a.dt, in_n, in_p, ap->phM[1][0], pxn, pxp, lo, mstore);
+                    term_u2<-1, T, V>(b, diff<T, V>(en[0], en_km[0]), false, zkh, lkh, face_z, 3, a.dtd[2], a.dt, ap->phM[1][2], ap->phM[1][2], pz, pz, lo, mstore);
                 }
                 stg_nt<T, V>(ap->Bn[1] + rb, lo, b);
             }
             if (row_lt) {
                 P b = bo_km[2];
                 if (bl_in) {
-                    term_u2<+1, T, V>(b, diff<T, V>(ex_jp, en_km[0]), false, zyh, lyh, face_y, 3, a.dtd[1], a.dt, ap->phM[2][1], ap->phM[2][1], py0, py1, lo, true);
-                    term_x3<-1, T, V>(b, diff_fwd_x<T, V>(en_km[1], ey_r), xs + 3 * TW, TW, pmz, a.dt, in_n, in_p, ap->phM[2][0], pxn, pxp, lo, true);
+                    term_u2<+1, T, V>(b, diff<T, V>(ex_jp, en_km[0]), false, zyh, lyh, face_y, 3, a.dtd[1], a.dt, ap->phM[2][1], ap->phM[2][1], py0, py1, lo, mstore);
+                    term_x3<-1, T, V>(b, diff_fwd_x<T, V>(en_km[1], ey_r), xs + 3 * TW, TW, pmz, a.dt, in_n, in_p, ap->phM[2][0], pxn, pxp, lo, mstore);
                 }
                 stg_nt<T, V>(ap->Bn[2] + rb, lo, b);
             }

@@ -195,7 +195,7 @@ class Engine3D(_Common):
         _check(lib().fdtd3d_step(self.h, C.c_int(n0), C.c_int(count), _stream_handle(stream)), "fdtd3d_step")
 
     def step_pairs(self, n0: int, pairs: int = 1, stream=None) -> None:
-        """Steps n0 .. n0+2*pairs-1, two per launch (fdtd3d_step_pairs: no CPML, whole grid, FUSED mode, no probes)."""
+        """Steps n0 .. n0+2*pairs-1, two per launch (fdtd3d_step_pairs: FUSED mode; probes only on a whole-grid engine)."""
         _check(lib().fdtd3d_step_pairs(self.h, C.c_int(n0), C.c_int(pairs), _stream_handle(stream)), "fdtd3d_step_pairs")
 
     def planes(self, id_: int, k: int, count: int = 1):

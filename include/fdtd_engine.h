@@ -135,12 +135,13 @@ int fdtd3d_step(fdtd3d_handle h, int n0, int count, void* stream);
 /* Steps n0 .. n0 + 2*pairs - 1 with TWO steps per launch (updateE, updateH, updateE, updateH of
  * FDTD3D.cpp:480-1021 for a cell before its neighbours' second step is due): D, B, eps and mu cross
  * device memory once per two steps; the results are those of 2*pairs calls of the one-step kernel, bit
- * for bit, CPML state included.  Restricted to what the kernel carries so far: FUSED mode, no probes
- * registered (a probe would have to be sampled between the two steps of a launch); on a slab see the
- * note on overlapping slabs below.  Anything else is refused with FDTD_ERR_STATE.  fdtd3d_step uses
- * these launches by itself for as many of its steps as it can when the engine holds the whole grid,
- * the grid is large enough for them to pay (384^3 cells; the environment variable FDTD_PAIR=0/1
- * overrides) and no probe is registered.
+ * for bit, CPML state included.  Restricted to FUSED mode; on a slab see the note on overlapping slabs
+ * below.  Anything else is refused with FDTD_ERR_STATE.  Registered probes are sampled after BOTH steps
+ * of a launch on an engine that holds the whole grid: the values after the first step, which never
+ * reach memory, are formed before the launch by one-plane launches of the one-step kernel over the
+ * planes that hold probes (a slab engine with probes is refused).  fdtd3d_step uses these launches by
+ * itself for as many of its steps as it can when the engine holds the whole grid and the grid is large
+ * enough for them to pay (384^3 cells; the environment variable FDTD_PAIR=0/1 overrides).
  * fdtd3d_pair_shape sets the planes per workgroup (default: chosen from the grid, at most 128) and the
  * waves per workgroup (6..16, default 16; three of them are halo rows); 0 keeps. */
 int fdtd3d_step_pairs(fdtd3d_handle h, int n0, int pairs, void* stream);

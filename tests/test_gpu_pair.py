@@ -1,4 +1,6 @@
 """Two steps per launch (fdtd3d_step_pairs) against the reference vectors, the twin and the one-step kernel (needs a GPU)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -179,10 +181,63 @@ def test_pairs_refuse_what_they_do_not_carry():
     lean = fdtd_amd.Engine3D((16, 16, 16), (0,) * 6, (1e-7,) * 3, 1e-16, K["mu0"], 4, 3, precision=32, mode=fdtd_amd.engine.MODE_LEAN)
     with pytest.raises(fdtd_amd.EngineError, match="FUSED"):
         lean.step_pairs(0, 1)
-    probed = fdtd_amd.Engine3D((16, 16, 16), (0,) * 6, (1e-7,) * 3, 1e-16, K["mu0"], 4, 3, precision=32, mode=MODE_FUSED)
+    probed = fdtd_amd.Engine3D((16, 16, 16), (0,) * 6, (1e-7,) * 3, 1e-16, K["mu0"], 4, 3, precision=32, mode=MODE_FUSED, z_range=(0, 8))
     probed.probe_add(po.DX, 3, 3, 3)
     with pytest.raises(fdtd_amd.EngineError, match="probes"):
         probed.step_pairs(0, 1)
+
+
+@pytest.mark.parametrize("prec,N,npml,has_mu", [
+    (32, (40, 21, 17), (5, 6, 4, 3, 3, 4), True),
+    (64, (30, 18, 22), (4, 4, 0, 5, 6, 0), False),
+    (32, (24, 20, 28), (0,) * 6, False),
+])
+def test_probe_series_of_pairs_equal_single_steps(prec, N, npml, has_mu):
+    """Probes on two-step launches: the sample after the first step of every launch comes from one-plane launches of
+    the one-step kernel before it (which must leave no trace), the sample after the second from the arrays.  The series
+    of D, E, B and H probes -- inside CPML layers, next to walls, several per plane -- and the final state equal those
+    of an engine that takes one step per launch; step() pairs by itself (FDTD_PAIR=1) and step_pairs() explicitly."""
+    K = po.consts()
+    d = (5e-8, 6e-8, 7e-8)
+    dt = 5e-8 / (2 * K["c0"])
+    steps = 15
+    kJ = N[2] // 2
+    rng = np.random.default_rng(5)
+    wf, mag = po.default_source3d(N[0], N[1], steps, d, dt)
+    mag = rng.random(mag.shape)
+    cells = [(po.DX, 1, 2, kJ), (po.EX, 3, 4, kJ), (po.EY, 2, 1, 1), (po.EZ, N[0] - 2, N[1] - 2, N[2] - 2), (po.BX, 1, 1, 1),
+             (po.HY, 2, 3, kJ), (po.HZ, N[0] - 2, 2, 2), (po.BZ, 4, N[1] - 2, N[2] - 1), (po.DZ, 5, 5, 0), (po.HX, 3, 3, N[2] - 1)]
+    runs = []
+    for mode in ("single", "auto", "explicit"):
+        os.environ["FDTD_PAIR"] = "0" if mode == "single" else "1"
+        try:
+            eng = fdtd_amd.Engine3D(N, npml, d, dt, K["mu0"], kJ, steps, precision=prec, mode=MODE_FUSED, has_mu=has_mu)
+            for a in range(3):
+                for s_ in range(2):
+                    if npml[a * 2 + s_]:
+                        tabs = po.cpml_face(npml[a * 2 + s_], s_, d[a], d[a], dt)
+                        for k in range(6):
+                            eng.set(po.tab_id(a, s_, k), tabs[k])
+            eng.set(po.JX_WF, wf)
+            eng.set(po.JX_MAG, mag)
+            eng.fill_materials(99, K["eps0"], 4 * K["eps0"], K["mu0"], (2 if has_mu else 1) * K["mu0"])
+            for c in cells:
+                eng.probe_add(*c)
+            if mode == "explicit":
+                eng.step_pairs(0, 3); eng.step(6, 1); eng.step_pairs(7, 4)
+            else:
+                eng.step(0, 7); eng.step(7, 8)
+            series = eng.probe_read()
+            state = {id_: eng.get(id_) for id_ in [po.DX, po.DY, po.DZ, po.BX, po.BY, po.BZ] + po.ALL_PHI3D if eng.size(id_)}
+            runs.append((series, state))
+        finally:
+            os.environ.pop("FDTD_PAIR", None)
+    assert runs[0][0].shape == (steps, len(cells))
+    assert np.any(runs[0][0] != 0)
+    for mode, (series, state) in zip(("auto", "explicit"), runs[1:]):
+        util.assert_equal_arrays(series, runs[0][0], f"probe series, {mode} pairs, N={N}")
+        for id_, v in state.items():
+            util.assert_equal_arrays(v, runs[0][1][id_], f"state after probed {mode} pairs, N={N}, array {id_}")
 
 
 @pytest.mark.parametrize("seed", range(24))
