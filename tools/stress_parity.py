@@ -1,15 +1,16 @@
-"""The suite's randomized parity tests (fused and two-kernel, 3-D whole grids and slab partitions, 2-D)
+"""The suite's randomized parity tests (fused, two steps per launch and two-kernel, 3-D whole grids and slab partitions, 2-D)
 over a range of further seeds:  python tools/stress_parity.py LO HI   (needs the GPU; ~8 seeds per second)."""
 import sys, time, traceback
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests import test_gpu_fused as tf, test_gpu_fused2d as t2, test_gpu_parity as tp, test_gpu_group as tg
+from tests import test_gpu_fused as tf, test_gpu_fused2d as t2, test_gpu_parity as tp, test_gpu_group as tg, test_gpu_pair as tq
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 t0 = time.time()
 for seed in range(lo, hi):
     for name, fn in (("fused3d", tf.test_fused_random_configurations_equal_twin), ("slabs3d", tf.test_fused_random_slab_partitions_equal_twin),
-                     ("group3d", tg.test_group_random_configurations_equal_twin)):
+                     ("group3d", tg.test_group_random_configurations_equal_twin),
+                     ("pairs3d", tq.test_pairs_equal_single_steps_random_configurations)):
         try:
             fn(seed)
         except Exception as e:
