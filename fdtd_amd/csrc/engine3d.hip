@@ -256,6 +256,7 @@ struct fdtd3d_engine {
     virtual bool pair_auto() = 0;
     virtual void pair_give_up() = 0;
     virtual void pair_info(int out[4]) = 0;
+    virtual void pair_layout(int out[4]) = 0;
     virtual int parity() = 0;
     virtual int fused_top(hipStream_t s) = 0;
     virtual int placement(double* ms, int cap) = 0;
@@ -1331,6 +1332,11 @@ struct Engine3 : fdtd3d_engine {
     }
     void pair_give_up() override { pair_off = true; (void)hipGetLastError(); }      // the failed allocation's error is not the next launch's
     void pair_info(int out[4]) override { out[0] = pair_auto() ? 1 : 0; out[1] = pair_chunk(); out[2] = wpbp; out[3] = V / 2; }
+    // tile order of the two-step kernel: as dealt (0: x tiles fastest, round-robin over the XCDs) with the x tiles in a
+    // row -- measured at 1024^3 with CPML: 12.3 ms against 12.7 with the x tiles of a row group kept on one XCD; with
+    // both strips in tile 0 the row group per XCD is the better one (11.2-11.3 against 11.4-11.6, three runs each)
+    int pair_remap(const PairTiles& t) const { return remap == kRemapAuto ? (t.wrap_l > 0 ? t.nbx : 0) : remap; }
+    void pair_layout(int out[4]) override { const PairTiles t = pair_tiles(); out[0] = t.nbx; out[1] = t.wrap_l; out[2] = t.wrap_r0; out[3] = pair_remap(t); }
     int step_pair(int n, hipStream_t s) override { return step_pair_part(n, FDTD3D_PART_ALL, s); }
     // One launch of the two-step kernel over the owned planes [r0, r1).
     int pair_launch(K3<T> a, int r0, int r1, int part, bool pml, hipStream_t s) {
@@ -1409,9 +1415,7 @@ struct Engine3 : fdtd3d_engine {
         a.wpb = wpbp;
         a.nby = (ny1 + (wpbp - 3) - 1) / (wpbp - 3);
         a.chunk = pair_chunk();
-        // tile order: as dealt (x tiles fastest, round-robin over the XCDs) -- measured at 1024^3 with CPML: 12.3 ms
-        // against 12.7 with the x tiles of a row group kept on one XCD
-        a.remap = remap == kRemapAuto ? 0 : remap;
+        a.remap = pair_remap(tiles);
         const int lo = 1, hi = last_rank ? nzp : nzp - 1;         // the owned planes (on a slab: see fdtd3d_step_pairs)
         const int cut = std::min(lo + kPairEdge, hi), cut2 = std::max(cut, hi - kPairEdge);
         int rc = FDTD_OK;
@@ -1567,6 +1571,11 @@ int fdtd3d_pair_part(fdtd3d_handle h, int n, int part, void* stream) {
 int fdtd3d_pair_info(fdtd3d_handle h, int out[4]) {
     if (!h || !out) return fail(FDTD_ERR_ARG, "null argument");
     h->pair_info(out);
+    return FDTD_OK;
+}
+int fdtd3d_pair_layout(fdtd3d_handle h, int out[4]) {
+    if (!h || !out) return fail(FDTD_ERR_ARG, "null argument");
+    h->pair_layout(out);
     return FDTD_OK;
 }
 int fdtd3d_pair_shape(fdtd3d_handle h, int chunk, int rows) { return entry(h, [&] { return h->pair_shape(chunk, rows); }); }

@@ -215,7 +215,10 @@ class Engine3D(_Common):
         """Whether step() goes two steps per launch on this engine, and the two-step kernel's launch shape."""
         o = (C.c_int * 4)()
         _check(lib().fdtd3d_pair_info(self.h, o), "fdtd3d_pair_info")
-        return dict(zip(("used_by_step", "planes_per_group", "rows_per_group", "elements_per_lane"), list(o)))
+        info = dict(zip(("used_by_step", "planes_per_group", "rows_per_group", "elements_per_lane"), list(o)))
+        _check(lib().fdtd3d_pair_layout(self.h, o), "fdtd3d_pair_layout")
+        info.update(zip(("x_tiles", "tile0_left_lanes", "tile0_right_from", "xcd_run"), list(o)))
+        return info
 
     def stamp_shape(self) -> dict:
         """Everything about the launch shapes a profiler pass has to share with a timed run to be quoted beside it."""

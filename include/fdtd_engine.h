@@ -165,6 +165,10 @@ int fdtd3d_pair_part(fdtd3d_handle h, int n, int part, void* stream);
 /* out = { 1 if fdtd3d_step takes its steps two per launch on this engine, planes per workgroup,
  *         waves per workgroup, elements per lane } of the two-step kernel. */
 int fdtd3d_pair_info(fdtd3d_handle h, int out[4]);
+/* out = { x tiles per row, lanes of tile 0 that hold the first columns of a row when that tile holds both ends
+ *         of it (0: the tiles lie in a row), first column of its other lanes, tiles per run handed to one XCD
+ *         (0: tiles are taken as dealt) } of the two-step kernel's next launch.  No counterpart in the reference. */
+int fdtd3d_pair_layout(fdtd3d_handle h, int out[4]);
 
 /* Half steps over a sub-range of the owned layers, for slab drivers that overlap the
  * ghost exchange with the interior update.  part: */
