@@ -579,7 +579,7 @@ struct Engine3 : fdtd3d_engine {
         int explore = 5;                 // placements timed before the first may be accepted
         if (const char* e = getenv("FDTD_PLACEMENT_EXPLORE")) { int v = atoi(e); if (v >= 1 && v <= 16) explore = v; }
         // Engines that hold a whole grid of >= 8 GiB spread their large arrays over physical memory instead (see
-        // place_spread): up to 6 GiB between two arrays, less where the device does not have that much free; no search
+        // place_spread): up to 10 GiB between two arrays, less where the device does not have that much free; no search
         // is needed then.  FDTD_SPREAD=0 turns it off, FDTD_SPREAD=1 also spreads slab engines and small ones,
         // FDTD_SPREAD_GAP_MB sets the gap.
         bool want_spread = arena_cap >= ((size_t)8 << 30) && d.z_lo == 0 && d.z_hi == d.Nz;
@@ -588,7 +588,10 @@ struct Engine3 : fdtd3d_engine {
         if (want_spread) {
             size_t free_b = 0, total_b = 0;
             FDTD_HIP(hipMemGetInfo(&free_b, &total_b));
-            size_t gap = (size_t)6 << 30;
+            // 10 GiB where there is room: on a box whose memory nothing has used yet, the two-step kernel runs the 1024^3
+            // grid in 11.12 ms per step with 10 GiB between the arrays, 11.17 with 8, 11.20 with 7, 11.34-11.47 with 6,
+            // 11.85 with 4 (the one-step kernel does not care beyond 6)
+            size_t gap = (size_t)10 << 30;
             if (const char* e = getenv("FDTD_SPREAD_GAP_MB")) gap = (size_t)std::max(0ll, atoll(e)) << 20;
             const size_t reserve = (size_t)2 << 30, n_gaps = big_starts.size() > 1 ? big_starts.size() - 1 : 1;
             const size_t room = free_b > arena_cap + reserve ? free_b - arena_cap - reserve : 0;
