@@ -578,11 +578,13 @@ struct Engine3 : fdtd3d_engine {
         if (const char* e = getenv("FDTD_PLACEMENT_TRIES")) { int v = atoi(e); if (v >= 1 && v <= 16) tries = v; }
         int explore = 5;                 // placements timed before the first may be accepted
         if (const char* e = getenv("FDTD_PLACEMENT_EXPLORE")) { int v = atoi(e); if (v >= 1 && v <= 16) explore = v; }
-        // Engines that hold a whole grid of >= 8 GiB spread their large arrays over physical memory instead (see
+        // Engines that hold a whole grid of >= 2 GiB spread their large arrays over physical memory instead (see
         // place_spread): up to 10 GiB between two arrays, less where the device does not have that much free; no search
         // is needed then.  FDTD_SPREAD=0 turns it off, FDTD_SPREAD=1 also spreads slab engines and small ones,
         // FDTD_SPREAD_GAP_MB sets the gap.
-        bool want_spread = arena_cap >= ((size_t)8 << 30) && d.z_lo == 0 && d.z_hi == d.Nz;
+        // (from 2 GiB: a 384^3 grid with CPML steps 6-7 % faster on spread arrays, one- and two-step kernel alike, 512^3
+        // without CPML 12 %; 256^3 and below do not notice; only gaps of about 10 GiB do it, 1-4 GiB change nothing)
+        bool want_spread = arena_cap >= ((size_t)2 << 30) && d.z_lo == 0 && d.z_hi == d.Nz;
         if (const char* e = getenv("FDTD_SPREAD")) want_spread = e[0] == '1';
         if (getenv("FDTD_PLACEMENT_SCAN_MB") || getenv("FDTD_NO_ARENA") || getenv("FDTD_PLACEMENT_TRIES") || gap_bytes) want_spread = want_spread && getenv("FDTD_SPREAD");
         if (want_spread) {
@@ -1300,9 +1302,15 @@ struct Engine3 : fdtd3d_engine {
         for (int m = 0; m < 2; ++m) for (int c = 0; c < 3; ++c) for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd)
             if (phSize[m][c][ax][sd] >= ((size_t)1 << 31)) return false;       // the kernel indexes the CPML state with 32 bits
         if (const char* e = getenv("FDTD_PAIR")) return atoi(e) != 0;
-        return (size_t)d.Nx * d.Ny * d.Nz >= kPairMinCells;
+        bool pml = false;
+        for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) pml = pml || np[ax][sd] != 0;
+        return (size_t)d.Nx * d.Ny * d.Nz >= (pml ? kPairMinCellsPml : kPairMinCells);
     }
+    // measured, two steps per launch against one: without CPML 384^3 0.71 against 1.03 ms per step (200^3: 0.33 against
+    // 0.24); with 20 layers on every face, where a third of the workgroups of a small grid run a layer loop, 384^3 1.39
+    // against 1.31, 448^3 1.73 against 1.73, 512^3 2.03 against 2.23, 640^3 3.87 against 4.77
     static constexpr size_t kPairMinCells = (size_t)384 * 384 * 384;
+    static constexpr size_t kPairMinCellsPml = (size_t)448 * 448 * 448;
     // x tiles of the two-step kernel: in a row, each overlapping the next by four columns; or, when both x faces carry
     // CPML layers and both strips fit one wave, tile 0 takes both ends of the row (its first `wrap_l` lanes the left
     // end, the others the columns from `wrap_r0` on, each part reaching four columns beyond its strip) and the other
@@ -1327,11 +1335,27 @@ struct Engine3 : fdtd3d_engine {
     int pair_nbx() const { return pair_tiles().nbx; }
     // planes per workgroup: long chunks amortise the three extra iterations of a chunk, but the launch should
     // still have a few workgroups per CU
+    // A CU holds one workgroup of the two-step kernel at a time, so a launch goes through the chip in rounds of as many
+    // workgroups as there are CUs: of the chunk counts around the one above, take the one whose last round is fullest
+    // (weighed against the three extra iterations every chunk costs).  512^3 without CPML: 5 chunks of 103 planes
+    // (1000 workgroups, 3.9 rounds) run in 1.21 ms per step, 6 chunks of 86 (4.7 rounds) in 1.23.
     int pair_chunk() const {
         if (chunk_pair > 0) return chunk_pair;
         const int per_layer = pair_nbx() * ((ny1 + (wpbp - 3) - 1) / (wpbp - 3));
         const int want = (1024 + per_layer - 1) / per_layer;
-        return std::max(8, std::min(128, (nzp - 1 + want - 1) / want));
+        const int planes = std::max(1, nzp - 1);
+        int cus = 0, dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        int best = std::max(8, std::min(128, (planes + want - 1) / want));
+        double best_cost = 1e30;
+        for (int nb = std::max(1, want - 1); nb <= want + 3; ++nb) {
+            const int c = (planes + nb - 1) / nb;
+            if (c > 128 || c < 8) continue;
+            const double groups = (double)per_layer * ((planes + c - 1) / c);
+            const double cost = std::ceil(groups / cus) * cus / groups * (c + 3.0) / c;
+            if (cost < best_cost - 1e-9) { best_cost = cost; best = c; }
+        }
+        return best;
     }
     void pair_give_up() override { pair_off = true; (void)hipGetLastError(); }      // the failed allocation's error is not the next launch's
     void pair_info(int out[4]) override { out[0] = pair_auto() ? 1 : 0; out[1] = pair_chunk(); out[2] = wpbp; out[3] = V / 2; }
