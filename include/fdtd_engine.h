@@ -141,7 +141,7 @@ int fdtd3d_step(fdtd3d_handle h, int n0, int count, void* stream);
  * reach memory, are formed before the launch by one-plane launches of the one-step kernel over the
  * planes that hold probes (a slab engine with probes is refused).  fdtd3d_step uses these launches by
  * itself for as many of its steps as it can when the engine holds the whole grid and the grid is large
- * enough for them to pay (384^3 cells; the environment variable FDTD_PAIR=0/1 overrides).
+ * enough for them to pay (384^3 cells, 448^3 with CPML layers; the environment variable FDTD_PAIR=0/1 overrides).
  * fdtd3d_pair_shape sets the planes per workgroup (default: chosen from the grid, at most 128) and the
  * waves per workgroup (6..16, default 16; three of them are halo rows); 0 keeps. */
 int fdtd3d_step_pairs(fdtd3d_handle h, int n0, int pairs, void* stream);
