@@ -139,8 +139,19 @@ struct Engine2 : fdtd2d_engine {
     int probe_read(double* out, size_t cap, int* n_samples, int* n_probes) override { return probes.read(out, cap, n_samples, n_probes); }
     int probe_reset(int drop_probes) override { probes.reset(drop_probes != 0); return FDTD_OK; }
 
+    // Arrays that are streamed at the same time stream faster when they lie far apart in physical memory (measured
+    // at 8192^2, fused stepping: 0.345 against 0.363 ms per step with 10 GiB between them; 2 or 6 GiB change nothing).
+    // While a large engine is set up, every field-sized allocation is therefore preceded by a throw-away one of
+    // `gap_bytes`, all of which are freed again at the end of init(): the driver hands memory out in order.
+    // FDTD2D_GAP_MB sets the gap (0: none).
+    std::vector<void*> gap_allocs;
+    size_t gap_bytes = 0;
     int dalloc(void** p, size_t nbytes) {
         if (nbytes == 0) { *p = nullptr; return FDTD_OK; }
+        if (gap_bytes && nbytes >= ((size_t)64 << 20)) {
+            void* g = nullptr;
+            if (hipMalloc(&g, gap_bytes) == hipSuccess) gap_allocs.push_back(g); else (void)hipGetLastError();     // no room: no gap here
+        }
         FDTD_HIP(hipMalloc(p, nbytes));
         allocs.push_back(*p);
         bytes += nbytes;
@@ -160,6 +171,16 @@ struct Engine2 : fdtd2d_engine {
         if (const char* e = getenv("FDTD_XCD_REMAP")) { int v = atoi(e); if (v >= 0 && v < 65536) { remap = v; remap_set = true; } }
         int rc;
         const size_t fb = (fsize + px) * sizeof(T);
+        struct GapGuard { std::vector<void*>& v; ~GapGuard() { for (void* g : v) (void)hipFree(g); v.clear(); } } gap_guard{gap_allocs};
+        if (fb >= ((size_t)64 << 20)) {
+            const size_t n_big = 18 + (d.mode == FDTD2D_MODE_FUSED ? 6 : 0), reserve = (size_t)4 << 30;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+            const size_t room = free_b > n_big * fb + reserve ? free_b - n_big * fb - reserve : 0;
+            gap_bytes = std::min((size_t)10 << 30, room / n_big);
+            if (const char* e = getenv("FDTD2D_GAP_MB")) gap_bytes = std::min((size_t)std::max(0ll, atoll(e)) << 20, room / n_big);
+            if (gap_bytes < ((size_t)1 << 30)) gap_bytes = 0;
+        }
         if ((rc = dalloc((void**)&Dy, fb)) || (rc = dalloc((void**)&Bx, fb)) || (rc = dalloc((void**)&Bz, fb))) return rc;
         for (int f = 0; f < 3; ++f) {
             if ((rc = dalloc((void**)&Fa[f], fb)) || (rc = dalloc((void**)&Fb[f], fb)) || (rc = dalloc((void**)&Sa[f], fb)) ||
@@ -190,6 +211,7 @@ struct Engine2 : fdtd2d_engine {
             if ((rc = upload_tables())) return rc;
         }
         Jy.assign(d.n_wf > 0 ? d.n_wf : 0, (T)0);
+        gap_bytes = 0;                       // later allocations (observables) are plain ones
         return FDTD_OK;
     }
     size_t device_bytes() override { return bytes; }
