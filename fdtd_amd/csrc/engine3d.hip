@@ -384,6 +384,8 @@ struct Engine3 : fdtd3d_engine {
     bool planning = false;
     static constexpr size_t kGranule = 4096;
     size_t gap_bytes = 0;
+    size_t plain_gap = 0;                // while set: every large stand-alone allocation is preceded by a throw-away one of this size
+    std::vector<void*> throwaway;
     int dalloc(void** p, size_t nbytes, int fill_byte_pattern_zero = 1) {
         if (nbytes == 0) { *p = nullptr; return FDTD_OK; }
         size_t span = (nbytes + kGranule - 1) / kGranule * kGranule;
@@ -394,7 +396,21 @@ struct Engine3 : fdtd3d_engine {
             arena_used += span;
             bytes += nbytes;
         } else {                            // arrays created after set-up (observables) stand alone
-            FDTD_HIP(hipMalloc(p, nbytes));
+            if (plain_gap && nbytes >= ((size_t)256 << 20)) {      // (see "slab engines" in init)
+                void* g = nullptr;
+                if (hipMalloc(&g, plain_gap) == hipSuccess) throwaway.push_back(g); else (void)hipGetLastError();   // no room: no gap here
+            }
+            *p = nullptr;
+            hipError_t got = hipMalloc(p, nbytes);
+            if (got != hipSuccess && !throwaway.empty()) {
+                // the gaps have taken what the arrays need: give them back and go on without
+                (void)hipGetLastError();
+                for (void* q : throwaway) (void)hipFree(q);
+                throwaway.clear();
+                plain_gap = 0;
+                got = hipMalloc(p, nbytes);
+            }
+            FDTD_HIP(got);
             allocs.push_back(*p);
             bytes += nbytes;
         }
@@ -608,6 +624,30 @@ struct Engine3 : fdtd3d_engine {
                     placement_log.push_back(ms);
                     fprintf(stderr, "[fdtd] arena spread over physical memory, %.2f GiB between large arrays: %.3f ms/step\n", spread_gap_gib, ms);
                 }
+                tries = 0;
+            }
+        }
+        // Slab engines: their planes travel between devices, and memory mapped through the virtual-memory API has not run
+        // under RCCL or peer copies between two real GPUs.  They get the same physical layout with ordinary allocations:
+        // every array an allocation of its own, each large one preceded by a throw-away allocation of the gap, all of
+        // which are freed once the arrays exist (the driver hands memory out in order).  One slab of the two-rank
+        // weak-scaling problem alone on a GPU: 11.3 ms per step against 11.6 on one arena after the timed search.
+        // FDTD_SLAB_GAP_MB sets the gap (0: one arena and the timed search, as before).
+        if (!vm_base && !(d.z_lo == 0 && d.z_hi == d.Nz) && arena_cap >= ((size_t)2 << 30) && !getenv("FDTD_SPREAD") &&
+            !getenv("FDTD_PLACEMENT_SCAN_MB") && !getenv("FDTD_NO_ARENA") && !getenv("FDTD_PLACEMENT_TRIES") && !gap_bytes) {
+            size_t free_b = 0, total_b = 0;
+            FDTD_HIP(hipMemGetInfo(&free_b, &total_b));
+            size_t gap = (size_t)10 << 30;
+            if (const char* e = getenv("FDTD_SLAB_GAP_MB")) gap = (size_t)std::max(0ll, atoll(e)) << 20;
+            const size_t reserve = std::max((size_t)6 << 30, total_b / 32), n_gaps = big_starts.size() > 1 ? big_starts.size() - 1 : 1;
+            const size_t room = free_b > arena_cap + reserve ? free_b - arena_cap - reserve : 0;
+            gap = std::min(gap, room / n_gaps);
+            if (gap >= ((size_t)1 << 30)) {
+                struct Guard { std::vector<void*>& v; size_t& g; ~Guard() { for (void* q : v) (void)hipFree(q); v.clear(); g = 0; } } guard{throwaway, plain_gap};
+                plain_gap = gap;
+                arena = nullptr; arena_cap = 0; arena_used = 0; bytes = 0;
+                if ((rc = allocate_all())) return rc;
+                spread_gap_gib = (double)gap / (double)((size_t)1 << 30);
                 tries = 0;
             }
         }
