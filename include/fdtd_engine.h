@@ -260,17 +260,20 @@ int fdtd3d_probe_reset(fdtd3d_handle h, int drop_probes);
 /* Placement of large engines (>= 8 GiB of device state).  The step kernels stream from all field arrays at once, and
  * the rate depends on how far apart those arrays lie in physical device memory: adjacent is slowest, a few GiB of other
  * memory between two arrays fastest (1024^3 fused step: 17.8 ms adjacent, 16.7 ms with 6 GiB between arrays).
- * An engine that holds a whole grid therefore backs its arrays through the virtual-memory API with physical chunks
- * created in order, and creates and releases up to 6 GiB of further chunks in front of every field array: the arrays end
- * up that far apart physically while the process only holds their own memory.  fdtd3d_spread_gap_gib() reports the gap
- * used (0 if the engine is not spread).  Environment: FDTD_SPREAD=0 off, FDTD_SPREAD=1 also for slab engines and small
- * ones, FDTD_SPREAD_GAP_MB the gap.  Memory backed this way must be opened to another device before that device can copy
+ * An engine that holds a whole grid (of 2 GiB or more) therefore backs its arrays through the virtual-memory API with
+ * physical chunks created in order, and creates and releases up to 10 GiB of further chunks in front of every field array:
+ * the arrays end up that far apart physically while the process only holds their own memory.  A slab engine (of 2 GiB or
+ * more) reaches the same layout with ordinary allocations -- every array a hipMalloc of its own, each large one behind a
+ * throw-away allocation of the gap, all of which are freed once the arrays exist -- because its planes travel between
+ * devices.  fdtd3d_spread_gap_gib() reports the gap used (0 if the arrays lie side by side).  Environment: FDTD_SPREAD=0
+ * off, FDTD_SPREAD=1 the virtual-memory way also for slab engines and small ones, FDTD_SPREAD_GAP_MB / FDTD_SLAB_GAP_MB
+ * the gap.  Memory backed this way must be opened to another device before that device can copy
  * to or from it: fdtd3d_grant_peer_access() (the slab group does it for neighbouring slabs). */
 double fdtd3d_spread_gap_gib(fdtd3d_handle h);
 int fdtd3d_grant_peer_access(fdtd3d_handle h, int peer_device);
 
-/* Engines that are not spread (slab engines; FDTD_SPREAD=0) are placed in device memory up to FDTD_PLACEMENT_TRIES
- * times (environment, default 8, 1 = off) at creation: where the driver puts a large allocation
+/* Large engines whose arrays share one allocation (FDTD_SPREAD=0, or FDTD_SLAB_GAP_MB=0 for slabs) are placed in device
+ * memory up to FDTD_PLACEMENT_TRIES times (environment, default 8, 1 = off) at creation: where the driver puts a large allocation
  * changes the streaming rate of the step kernels by several percent, so each placement is timed with
  * a few source-free steps on the zero state and, after five, the first one in the fast fifth of the
  * range seen is kept.
