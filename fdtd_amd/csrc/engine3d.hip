@@ -4,7 +4,9 @@
 #include "../../include/fdtd_setup.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -409,6 +411,12 @@ struct Engine3 : fdtd3d_engine {
                 throwaway.clear();
                 plain_gap = 0;
                 got = hipMalloc(p, nbytes);
+                // (another process setting up an engine on the same device holds its own gaps for a moment)
+                for (int t = 0; got != hipSuccess && t < 30; ++t) {
+                    (void)hipGetLastError();
+                    std::this_thread::sleep_for(std::chrono::milliseconds(100));
+                    got = hipMalloc(p, nbytes);
+                }
             }
             FDTD_HIP(got);
             allocs.push_back(*p);
