@@ -31,9 +31,18 @@ For N > 1 the line carries multi_gpu: backend and world size actually seen, and 
 time of every kind of launch, the time its stream sat idle in front of the launches that wait for a ghost plane,
 and the host time spent waiting for exchanges.
 
-Started WITHOUT torch.distributed.run but with --gpus N > 1, the same workload runs as ONE process
-driving N GPUs through a slab group (fdtd3d_group_*: streams, events, peer copies instead of RCCL);
-the JSON line then says so in config.decomposition.
+Started WITHOUT torch.distributed.run but with --gpus N > 1, this program starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process -- before it has touched
+a GPU itself -- and relays the child's JSON line, so a plain `python bench.py --gpus N` measures the same
+one-process-per-GPU path (two steps per launch on overlapping slabs) as the launcher form.
+FDTD_BENCH_GROUP=1 instead runs the workload as ONE process driving N GPUs through a slab group
+(fdtd3d_group_*: streams, events, peer copies instead of RCCL); the JSON line then says so in
+config.decomposition.
+
+At N = 1 the line also carries `extra`: bounded secondary legs timed by the same program after the headline
+engine has been released (FDTD_BENCH_EXTRA=0 skips them): the headline grid in fp64 (the precision that
+matches the reference bit for bit), the 512^3 vacuum cavity, and the 8192^2 2-D grid with CPML (reference
+slab and dispersive-everywhere materials).
 """
 import argparse
 import json
@@ -194,12 +203,151 @@ def roofline_block(eng, mode_name, has_mu, cells_local, steps, applies_traffic, 
             "whole_step_frac": (total_cells * (ref_e + ref_h) * steps / el / 1e9) / (HBM_PEAK_GBS * world) if el > 0 else 0.0}
 
 
+def _timed_steps(torch, eng, warm: int, steps: int):
+    """(wall seconds, device seconds of the step kernels) of `steps` steps after `warm` untimed ones."""
+    eng.step(0, warm)
+    torch.cuda.synchronize()
+    eng.kernel_timing(True)
+    t0 = time.perf_counter()
+    eng.step(warm, steps)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    eng.kernel_timing(False)
+    dev_ms = sum(eng.kernel_time(kind)[1] for kind in (0, 1, 2, 3))
+    return el, dev_ms * 1e-3
+
+
+def extra_legs(torch, scale: str):
+    """Secondary measurements for the one JSON line (N = 1 only, a few seconds each, after the headline engine has
+    been released).  `scale` = "full": the sizes the configurations are quoted on; "small": the same code on small
+    grids (tests).  A leg that fails reports its error instead of taking the headline down with it."""
+    import numpy as np
+    import fdtd_amd
+    from fdtd_amd import engine as E
+    from fdtd_amd import setup as fs
+    K = fs.constants()
+    d = (1053e-9 / 20,) * 3
+    dt = d[0] / (K["c0"] * 2.0)
+    full = scale == "full"
+    out = {}
+
+    def leg3d(name, N, npml, precision, has_mu, dipole, warm, steps, words, note):
+        try:
+            n_total = warm + steps
+            eng = fdtd_amd.Engine3D(N, npml, d, dt, K["mu0"], N[2] // 2 if dipole else 20, n_total, precision=precision,
+                                    has_mu=has_mu, mode=E.MODE_FUSED, device=torch.cuda.current_device())
+            try:
+                if any(npml):
+                    fs.load_cpml3d(eng, d, dt)
+                wf, mag = fs.default_source3d(N[0], N[1], n_total, d, dt)
+                if dipole:
+                    mag[:] = 0
+                    mag[N[0] // 2, N[1] // 2] = 1.0
+                eng.set(E.JX_WF, wf)
+                eng.set(E.JX_MAG, mag)
+                if dipole:
+                    eng.fill_materials(1234, K["eps0"], K["eps0"], K["mu0"], K["mu0"])
+                else:
+                    eng.fill_materials(1234, K["eps0"], 4.0 * K["eps0"], K["mu0"], 2.0 * K["mu0"])
+                el, dev_s = _timed_steps(torch, eng, warm, steps)
+                cells = N[0] * N[1] * N[2]
+                bpc = words * (precision // 8)              # the reference formulation's bytes per cell and step
+                ss, cs = eng.sumsq(E.DX), eng.checksum(E.DX)
+                out[name] = {"workload": note, "grid": list(N), "dtype": f"f{precision}", "steps": steps, "warmup": warm,
+                             "ms_per_step": el / steps * 1e3, "value": cells * steps / el / 1e6, "unit": "Mcell-updates/s",
+                             "kernel_ms_per_step": dev_s / steps * 1e3, "steps_per_launch": 2 if eng.pair_info()["used_by_step"] else 1,
+                             "roofline": {"bound": "hbm", "algorithmic_bytes_per_cell": bpc, "achieved": cells * bpc * steps / dev_s / 1e9,
+                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cells * bpc * steps / dev_s / 1e9 / HBM_PEAK_GBS},
+                             "device_bytes": eng.device_bytes(), "physical_gap_between_arrays_gib": eng.spread_gap_gib(),
+                             "checks": {"finite": bool(np.isfinite(ss)), "sumsq_dx": ss, "checksum_dx": cs}}
+            finally:
+                eng.close()
+        except Exception as e:          # noqa: BLE001 -- reported in the line
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+
+    def leg2d(name, N, material, warm, steps):
+        try:
+            dx = K["c0"] / 1.5e14 / 40
+            dt2 = dx / (2 * K["c0"])
+            eng = fdtd_amd.Engine2D(N, N, (20,) * 4, dx, dx, dt2, K["mu0"], K["eps0"], max(N // 2 - 40, 1), N // 2, steps + warm,
+                                    precision=32, mode=E.MODE2D_FUSED, device=torch.cuda.current_device())
+            try:
+                fs.load_cpml2d(eng, dx, dx, dt2)
+                eng.set(E.D2_JY, fs.default_source2d(steps + warm, dx, dx, dt2))
+                coef = fs.default_lorentz2d(N, N, dt2)
+                if material == "everywhere":
+                    coef = [np.full((N, N), c[N // 2, 0]) for c in coef]
+                n_disp = int(np.count_nonzero((coef[0] != 0) | (coef[1] != 0) | (coef[2] != 0)))
+                for q, c in enumerate(coef):
+                    eng.set(E.D2_C1 + q, c)
+                del coef
+                el, dev_s = _timed_steps(torch, eng, warm, steps)
+                cells = N * N
+                alg = n_disp * 132 + (cells - n_disp) * 24      # dispersive cell 33 words, plain cell 6 words (fp32)
+                ss = eng.sumsq(E.D2_EY)
+                out[name] = {"workload": f"fdtd2d {N}x{N}, 20-layer CPML on four sides, "
+                                         + ("reference Lorentz slab (41 columns), plain elsewhere" if material == "slab" else "Lorentz-dispersive at every cell"),
+                             "grid": [N, N], "dtype": "f32", "steps": steps, "warmup": warm, "ms_per_step": el / steps * 1e3,
+                             "value": cells * steps / el / 1e6, "unit": "Mcell-updates/s", "kernel_ms_per_step": dev_s / steps * 1e3,
+                             "dispersive_cells": n_disp,
+                             "roofline": {"bound": "hbm", "kernel": "k2_fused", "algorithmic_bytes_per_launch": alg,
+                                          "algorithmic_bytes_per_dispersive_cell": 132, "algorithmic_bytes_per_plain_cell": 24,
+                                          "achieved": alg * steps / dev_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": alg * steps / dev_s / 1e9 / HBM_PEAK_GBS},
+                             "checks": {"finite": bool(np.isfinite(ss)), "sumsq_ey": ss}}
+            finally:
+                eng.close()
+        except Exception as e:          # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+
+    n3, nc, n2 = (1024, 512, 8192) if full else (96, 64, 512)
+    leg3d("fp64_1024" if full else "fp64_small", (n3,) * 3, (20,) * 6 if full else (6,) * 6, 64, True, False, 4, 10, 30,
+          f"the headline configuration in fp64, the precision in which the engine equals the reference bit for bit: {n3}^3, eps/mu grids, CPML on six faces")
+    leg3d("cavity_512" if full else "cavity_small", (nc,) * 3, (0,) * 6, 32, False, True, 10, 100 if full else 10, 27,
+          f"vacuum cavity {nc}^3, PEC walls (no CPML), one-cell Jx dipole at the centre, constant mu0")
+    leg2d("fdtd2d_8192" if full else "fdtd2d_small", n2, "slab", 10, 100 if full else 10)
+    leg2d("fdtd2d_8192_dispersive_everywhere" if full else "fdtd2d_small_dispersive_everywhere", n2, "everywhere", 10, 60 if full else 10)
+    return out
+
+
+def relaunch_one_process_per_gpu(args) -> int:
+    """`python bench.py --gpus N` without a launcher: run the launcher form as a child and relay its one JSON
+    line.  Nothing in this process has touched a GPU yet (torch is not even imported), so starting a child is safe."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    if env.get("FDTD_BENCH_ONE_DEVICE", "0") == "1":
+        env.setdefault("FDTD_BENCH_BACKEND", "gloo")      # RCCL refuses two ranks on one device
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    child = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for ln in child.stdout:
+        if ln.startswith("{"):
+            lines.append(ln)
+        else:
+            sys.stderr.write(ln)          # launcher chatter stays off this program's stdout: one JSON line only
+    rc = child.wait()
+    for ln in lines[-1:]:
+        rec = json.loads(ln)
+        rec.setdefault("config", {})["launched_as"] = "child torch.distributed.run of a plain `bench.py --gpus N`"
+        print(json.dumps(rec))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("FDTD_BENCH_GROUP", "0") != "1":
+        sys.exit(relaunch_one_process_per_gpu(args))
 
     import torch
     import torch.distributed as dist
@@ -314,7 +462,7 @@ def main():
         mine = {"rank": rank, "device": torch.cuda.current_device(), "device_name": torch.cuda.get_device_name(),
                 "layers": [z_lo, z_hi], "stored_layers": list(stored), "stepper": type(stepper).__name__, "wall_ms_per_step": el_own / k * 1e3, "host_issue_ms_per_step": t_issue / k * 1e3,
                 "host_wait_ms_per_step": slab.WAIT_CLOCK["seconds"] / k * 1e3, "exchange_waits_per_step": slab.WAIT_CLOCK["calls"] / k,
-                "kernel_ms_per_step": roof["kernel_ms_per_step"], "placement_probe_ms": [round(v, 3) for v in eng.placement_probes()],
+                "kernel_ms_per_step": roof["kernel_ms_per_step"], "physical_gap_per_array_gib": [round(v, 2) for v in eng.spread_gaps()],
                 "checksum_dx": csum, **launches}
         parts = [None] * world
         dist.all_gather_object(parts, mine)
@@ -336,8 +484,11 @@ def main():
                                             + ("one kernel per TWO steps (k3_pair)" if roof["kernel"] == "k3_pair" else "one kernel per step"),
                                    "lean": "D,B resident; E=D/eps, H=B/mu recomputed in the consuming kernel; two kernels per step",
                                    "full": "D,E,B,H resident; two kernels per step"}[mode_name],
+                       "parity_mode": "fp32 (as the metric is worded): equals an fp32 restatement of the reference's loops bit for bit; "
+                                      "within 1e-6 relative L2 of the fp64 reference for about 700 steps of its default 3-D problem "
+                                      "(4e-8*sqrt(steps)).  precision=64 equals the reference bit for bit over its whole run: extra.fp64_1024",
                        "launch_shape": eng.stamp_shape(),
-                       "device_bytes_per_gpu": eng.device_bytes(), "placement_probe_ms": [round(v, 3) for v in eng.placement_probes()],
+                       "device_bytes_per_gpu": eng.device_bytes(), "physical_gap_per_array_gib": [round(v, 2) for v in eng.spread_gaps()],
                        "physical_gap_between_arrays_gib": eng.spread_gap_gib()},
             "roofline": roof,
             "launches": launches,
@@ -345,6 +496,10 @@ def main():
         }
         if multi is not None:
             out["multi_gpu"] = multi
+        extra_scale = os.environ.get("FDTD_BENCH_EXTRA", "full" if (n_edge == 1024 and mode_name == "fused") else "0")
+        if world == 1 and extra_scale in ("full", "small", "1"):
+            eng.close()                   # the secondary legs need the memory (fp64 at 1024^3 holds 161 GB)
+            out["extra"] = extra_legs(torch, "small" if extra_scale == "small" else "full")
         if world == 1 and os.environ.get("FDTD_BENCH_CPU", "1") != "0":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
@@ -397,7 +552,7 @@ def main_group(args):
         roof = roofline_block(m, mode_name, has_mu, Nx * Ny * (hi - lo), args.steps, False, len(set(devices)), Nx * Ny * Nz, el)
         roofs.append(roof)
         per_slab.append({"slab": r, "device": devices[r], "layers": [lo, hi], "kernel_ms_per_step": roof["kernel_ms_per_step"],
-                         "placement_probe_ms": [round(v, 3) for v in m.placement_probes()], **launches})
+                         "physical_gap_per_array_gib": [round(v, 2) for v in m.spread_gaps()], **launches})
     roof = min(roofs, key=lambda q: q["achieved"])          # the slowest slab's kernels set the pace
     roof["per_slab_GBs"] = [q["achieved"] for q in roofs]
     sums = [g.sumsq(i) for i in (E.DX, E.BY)]

@@ -4,9 +4,7 @@
 #include "../../include/fdtd_setup.h"
 
 #include <algorithm>
-#include <chrono>
 #include <cmath>
-#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -240,6 +238,16 @@ static int static_scratch(int dev, double** out) {
     return FDTD_OK;
 }
 
+// Scratch memory of a two-step launch with CPML: 24 row segments (12 terms x 2 planes in flight) of one wave's
+// columns per wave.  The kernel forms a wave's offset into it in 32 bits, so the whole piece must stay below 2^32
+// elements (a 1024^3 grid at the default 128 planes per workgroup needs 0.35e9; 8 planes per workgroup would need 4.5e9).
+extern "C" int fdtd3d_pair_scratch_fits(long long workgroups, int waves_per_group, int precision_bits) {
+    if (workgroups < 0 || waves_per_group < 1 || (precision_bits != 32 && precision_bits != 64)) return 0;
+    const unsigned long long tw = (unsigned long long)kLanes * (precision_bits == 32 ? 2 : 1);      // columns a wave computes
+    const unsigned long long per_group = (unsigned long long)waves_per_group * 24ull * tw;
+    return (unsigned long long)workgroups <= (((1ull << 32) - 1) / per_group) ? 1 : 0;
+}
+
 struct fdtd3d_engine {
     virtual ~fdtd3d_engine() {}
     virtual size_t array_size(int id) = 0;
@@ -261,7 +269,7 @@ struct fdtd3d_engine {
     virtual void pair_layout(int out[4]) = 0;
     virtual int parity() = 0;
     virtual int fused_top(hipStream_t s) = 0;
-    virtual int placement(double* ms, int cap) = 0;
+    virtual int gaps(double* gib, int cap) = 0;
     virtual int probe_add(int id, int i, int j, int k) = 0;
     virtual int probe_record(hipStream_t s) = 0;
     virtual int probe_read(double* out, size_t cap, int* n_samples, int* n_probes) = 0;
@@ -385,38 +393,32 @@ struct Engine3 : fdtd3d_engine {
     size_t arena_cap = 0, arena_used = 0;
     bool planning = false;
     static constexpr size_t kGranule = 4096;
-    size_t gap_bytes = 0;
     size_t plain_gap = 0;                // while set: every large stand-alone allocation is preceded by a throw-away one of this size
     std::vector<void*> throwaway;
     int dalloc(void** p, size_t nbytes, int fill_byte_pattern_zero = 1) {
         if (nbytes == 0) { *p = nullptr; return FDTD_OK; }
-        size_t span = (nbytes + kGranule - 1) / kGranule * kGranule;
-        if (nbytes >= ((size_t)256 << 20)) span += gap_bytes;      // experiment: spread the big arrays
-        if (planning) { if (nbytes >= ((size_t)256 << 20)) big_starts.push_back(arena_used); arena_used += span; *p = nullptr; return FDTD_OK; }
+        const size_t span = (nbytes + kGranule - 1) / kGranule * kGranule;
+        const bool big = nbytes >= ((size_t)256 << 20);
+        if (planning) { if (big) big_starts.push_back(arena_used); arena_used += span; *p = nullptr; return FDTD_OK; }
         if (arena && arena_used + span <= arena_cap) {
             *p = arena + arena_used;
             arena_used += span;
             bytes += nbytes;
-        } else {                            // arrays created after set-up (observables) stand alone
-            if (plain_gap && nbytes >= ((size_t)256 << 20)) {      // (see "slab engines" in init)
+        } else {                            // arrays created after set-up (observables) and the arrays of a slab engine stand alone
+            if (plain_gap && big) {         // (see "Placement" in init)
                 void* g = nullptr;
-                if (hipMalloc(&g, plain_gap) == hipSuccess) throwaway.push_back(g); else (void)hipGetLastError();   // no room: no gap here
+                if (hipMalloc(&g, plain_gap) == hipSuccess) { throwaway.push_back(g); gap_log.push_back((double)plain_gap / (double)((size_t)1 << 30)); }
+                else { (void)hipGetLastError(); gap_log.push_back(0.0); }   // no room: no gap here
             }
             *p = nullptr;
             hipError_t got = hipMalloc(p, nbytes);
             if (got != hipSuccess && !throwaway.empty()) {
-                // the gaps have taken what the arrays need: give them back and go on without
+                // the gaps have taken what the arrays need: give them back at once and go on without
                 (void)hipGetLastError();
                 for (void* q : throwaway) (void)hipFree(q);
                 throwaway.clear();
                 plain_gap = 0;
                 got = hipMalloc(p, nbytes);
-                // (another process setting up an engine on the same device holds its own gaps for a moment)
-                for (int t = 0; got != hipSuccess && t < 30; ++t) {
-                    (void)hipGetLastError();
-                    std::this_thread::sleep_for(std::chrono::milliseconds(100));
-                    got = hipMalloc(p, nbytes);
-                }
             }
             FDTD_HIP(got);
             allocs.push_back(*p);
@@ -426,30 +428,12 @@ struct Engine3 : fdtd3d_engine {
         return FDTD_OK;
     }
 
-    std::vector<double> placement_log;   // ms per probe step of every placement tried
-    int placement(double* ms, int cap) override {
-        for (int q = 0; q < cap && q < (int)placement_log.size(); ++q) ms[q] = placement_log[q];
-        return (int)placement_log.size();
-    }
-    // Four steps with the source off on the all-zero state: timing only, the state stays zero.
-    int probe(double* ms_per_step) {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        FDTD_HIP(hipEventCreate(&e0));
-        if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(FDTD_ERR_HIP, "hipEventCreate failed"); }
-        const int n_off = (int)wf.size();          // past the waveform: no source term
-        int rc = step(n_off, 0);                   // warm-up: code objects, first touch
-        if (!rc) rc = step(n_off, 0);
-        float ms = 0;
-        hipError_t he = hipEventRecord(e0, 0);
-        for (int q = 0; q < 4 && !rc; ++q) rc = step(n_off, 0);
-        if (he == hipSuccess) he = hipEventRecord(e1, 0);
-        if (he == hipSuccess) he = hipEventSynchronize(e1);
-        if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-        if (rc) return rc;
-        if (he != hipSuccess) return fail(FDTD_ERR_HIP, "timing a placement failed: %s", hipGetErrorString(he));
-        *ms_per_step = ms / 4;
-        return FDTD_OK;
+    // GiB of physical memory left out in front of every large array but the first, in allocation order (empty: the
+    // engine's memory is one plain allocation): what a run that streams slower than expected should look at first
+    std::vector<double> gap_log;
+    int gaps(double* gib, int cap) override {
+        for (int q = 0; q < cap && q < (int)gap_log.size(); ++q) gib[q] = gap_log[q];
+        return (int)gap_log.size();
     }
 
     // Spread placement.  The step kernels stream from all large arrays at once, and how fast that goes depends on how
@@ -461,8 +445,9 @@ struct Engine3 : fdtd3d_engine {
     // `gap` bytes worth of chunks are created too and released again as soon as the whole arena is mapped: the virtual
     // layout stays compact, the process only holds the memory of the arrays, and the arrays lie `gap` apart physically.
     // Returns FDTD_OK with vm_base == nullptr if the device cannot do it (the caller falls back to one allocation).
+    static constexpr size_t kVmChunk = (size_t)128 << 20;
     int place_spread(size_t gap) {
-        constexpr size_t kChunk = (size_t)128 << 20;
+        constexpr size_t kChunk = kVmChunk;
         hipMemAllocationProp prop = {};
         prop.type = hipMemAllocationTypePinned;
         prop.location.type = hipMemLocationTypeDevice;
@@ -479,10 +464,12 @@ struct Engine3 : fdtd3d_engine {
         for (size_t off = 0; off < total && ok; off += kChunk) {
             // a chunk in which the next large array begins: leave `gap` of physical memory out before it
             while (next_big < big_starts.size() && big_starts[next_big] < off + kChunk) {
+                size_t made = 0;
                 for (size_t g = 0; g < gap_chunks && ok; ++g) {
                     hipMemGenericAllocationHandle_t h;
-                    if (hipMemCreate(&h, kChunk, &prop, 0) == hipSuccess) dropped.push_back(h); else { (void)hipGetLastError(); g = gap_chunks; }   // out of memory: smaller gaps from here on
+                    if (hipMemCreate(&h, kChunk, &prop, 0) == hipSuccess) { dropped.push_back(h); ++made; } else { (void)hipGetLastError(); g = gap_chunks; }   // out of memory: smaller gaps from here on
                 }
+                gap_log.push_back((double)(made * kChunk) / (double)((size_t)1 << 30));
                 ++next_big;
             }
             hipMemGenericAllocationHandle_t h;
@@ -503,10 +490,10 @@ struct Engine3 : fdtd3d_engine {
             if (mapped) (void)hipMemUnmap(base, mapped);
             for (auto h : vm_chunks) (void)hipMemRelease(h);
             (void)hipMemAddressFree(base, total);
-            vm_base = nullptr; vm_size = 0; vm_chunks.clear();
+            vm_base = nullptr; vm_size = 0; vm_chunks.clear(); gap_log.clear();
             return FDTD_OK;
         }
-        spread_gap_gib = (double)(gap_chunks * kChunk) / (double)((size_t)1 << 30);
+        spread_gap_gib = gap_log.empty() ? 0.0 : *std::min_element(gap_log.begin(), gap_log.end());
         return FDTD_OK;
     }
     // Lets device `peer` read and write the arena (copies between the devices of neighbouring slabs).
@@ -587,31 +574,22 @@ struct Engine3 : fdtd3d_engine {
         if (const char* e = getenv("FDTD_ROWS_PER_GROUP")) { int w = atoi(e); if (w >= 1 && w <= 4) wpb = w; }
 
         int rc;
-        if (const char* e = getenv("FDTD_ARENA_GAP_KB")) gap_bytes = (size_t)atoll(e) << 10;
         planning = true; arena_used = 0; big_starts.clear();
         if ((rc = allocate_all())) return rc;
         planning = false;
         arena_cap = arena_used;
-        // Where the driver places a large allocation in physical memory changes the streaming rate of
-        // the step kernels by up to 10 % (measured: the same binary and virtual address run a 1024^3 step
-        // in 18.1, 18.9 or 20.0 ms, cycling with every free + allocate, across processes).  For large
-        // grids the arena is therefore placed a few times, each placement timed with four source-free
-        // steps on the zero state (which they leave unchanged); after five placements the first one in
-        // the fast fifth of the range seen so far is kept (an earlier placement cannot be returned to).
-        int tries = arena_cap >= ((size_t)8 << 30) ? 8 : 1;
-        if (const char* e = getenv("FDTD_PLACEMENT_TRIES")) { int v = atoi(e); if (v >= 1 && v <= 16) tries = v; }
-        int explore = 5;                 // placements timed before the first may be accepted
-        if (const char* e = getenv("FDTD_PLACEMENT_EXPLORE")) { int v = atoi(e); if (v >= 1 && v <= 16) explore = v; }
-        // Engines that hold a whole grid of >= 2 GiB spread their large arrays over physical memory instead (see
-        // place_spread): up to 10 GiB between two arrays, less where the device does not have that much free; no search
-        // is needed then.  FDTD_SPREAD=0 turns it off, FDTD_SPREAD=1 also spreads slab engines and small ones,
-        // FDTD_SPREAD_GAP_MB sets the gap.
-        // (from 2 GiB: a 384^3 grid with CPML steps 6-7 % faster on spread arrays, one- and two-step kernel alike, 512^3
-        // without CPML 12 %; 256^3 and below do not notice; only gaps of about 10 GiB do it, 1-4 GiB change nothing)
-        bool want_spread = arena_cap >= ((size_t)2 << 30) && d.z_lo == 0 && d.z_hi == d.Nz;
-        if (const char* e = getenv("FDTD_SPREAD")) want_spread = e[0] == '1';
-        if (getenv("FDTD_PLACEMENT_SCAN_MB") || getenv("FDTD_NO_ARENA") || getenv("FDTD_PLACEMENT_TRIES") || gap_bytes) want_spread = want_spread && getenv("FDTD_SPREAD");
-        if (want_spread) {
+        // Placement.  The step kernels stream from all field arrays at once, and how fast that goes depends on how far
+        // apart those arrays lie in PHYSICAL device memory (place_spread).  Engines of 2 GiB or more therefore lay their
+        // large arrays up to 10 GiB apart, less where the device does not have that much free: an engine that holds a
+        // whole grid through the virtual-memory API, a slab engine -- whose planes travel between devices -- with
+        // ordinary allocations and throw-away gaps.  Everything else, and any engine for which no gap of a useful size
+        // is left, is one plain allocation.  (A 384^3 grid with CPML steps 6-7 % faster on spread arrays, 512^3 without
+        // CPML 12 %; 256^3 and below do not notice; only gaps of about 10 GiB do it, 1-4 GiB change nothing.)
+        // FDTD_SPREAD=0: never; FDTD_SPREAD=1: the virtual-memory way for every engine; FDTD_SPREAD_GAP_MB: the gap.
+        const bool whole = d.z_lo == 0 && d.z_hi == d.Nz;
+        int spread = arena_cap >= ((size_t)2 << 30) ? (whole ? 2 : 1) : 0;       // 2: virtual-memory API, 1: throw-away gaps
+        if (const char* e = getenv("FDTD_SPREAD")) spread = e[0] == '1' ? 2 : 0;
+        if (spread) {
             size_t free_b = 0, total_b = 0;
             FDTD_HIP(hipMemGetInfo(&free_b, &total_b));
             // 10 GiB where there is room: on a box whose memory nothing has used yet, the two-step kernel runs the 1024^3
@@ -619,100 +597,34 @@ struct Engine3 : fdtd3d_engine {
             // 11.85 with 4 (the one-step kernel does not care beyond 6)
             size_t gap = (size_t)10 << 30;
             if (const char* e = getenv("FDTD_SPREAD_GAP_MB")) gap = (size_t)std::max(0ll, atoll(e)) << 20;
-            const size_t reserve = (size_t)2 << 30, n_gaps = big_starts.size() > 1 ? big_starts.size() - 1 : 1;
+            const size_t reserve = spread == 2 ? (size_t)2 << 30 : std::max((size_t)6 << 30, total_b / 32);
+            const size_t n_gaps = big_starts.size() > 1 ? big_starts.size() - 1 : 1;
             const size_t room = free_b > arena_cap + reserve ? free_b - arena_cap - reserve : 0;
             gap = std::min(gap, room / n_gaps);
-            if ((rc = place_spread(gap))) return rc;
-            if (vm_base) {
-                arena = vm_base; arena_used = 0; bytes = 0;
-                if ((rc = allocate_all())) return rc;
-                if (getenv("FDTD_PLACEMENT_DEBUG")) {
-                    double ms = 0;
-                    if ((rc = probe(&ms))) return rc;
-                    placement_log.push_back(ms);
-                    fprintf(stderr, "[fdtd] arena spread over physical memory, %.2f GiB between large arrays: %.3f ms/step\n", spread_gap_gib, ms);
+            if (spread == 2 && gap >= kVmChunk) {
+                if ((rc = place_spread(gap))) return rc;
+                if (vm_base) {
+                    arena = vm_base; arena_used = 0; bytes = 0;
+                    if ((rc = allocate_all())) return rc;
                 }
-                tries = 0;
-            }
-        }
-        // Slab engines: their planes travel between devices, and memory mapped through the virtual-memory API has not run
-        // under RCCL or peer copies between two real GPUs.  They get the same physical layout with ordinary allocations:
-        // every array an allocation of its own, each large one preceded by a throw-away allocation of the gap, all of
-        // which are freed once the arrays exist (the driver hands memory out in order).  One slab of the two-rank
-        // weak-scaling problem alone on a GPU: 11.3 ms per step against 11.6 on one arena after the timed search.
-        // FDTD_SLAB_GAP_MB sets the gap (0: one arena and the timed search, as before).
-        if (!vm_base && !(d.z_lo == 0 && d.z_hi == d.Nz) && arena_cap >= ((size_t)2 << 30) && !getenv("FDTD_SPREAD") &&
-            !getenv("FDTD_PLACEMENT_SCAN_MB") && !getenv("FDTD_NO_ARENA") && !getenv("FDTD_PLACEMENT_TRIES") && !gap_bytes) {
-            size_t free_b = 0, total_b = 0;
-            FDTD_HIP(hipMemGetInfo(&free_b, &total_b));
-            size_t gap = (size_t)10 << 30;
-            if (const char* e = getenv("FDTD_SLAB_GAP_MB")) gap = (size_t)std::max(0ll, atoll(e)) << 20;
-            const size_t reserve = std::max((size_t)6 << 30, total_b / 32), n_gaps = big_starts.size() > 1 ? big_starts.size() - 1 : 1;
-            const size_t room = free_b > arena_cap + reserve ? free_b - arena_cap - reserve : 0;
-            gap = std::min(gap, room / n_gaps);
-            if (gap >= ((size_t)1 << 30)) {
+            } else if (spread == 1 && gap >= ((size_t)1 << 30)) {
+                // every array an allocation of its own, each large one preceded by a throw-away allocation of the gap, all
+                // of which are freed once the arrays exist (the driver hands memory out in order); if an array does not
+                // fit any more, dalloc gives the gaps back at once and the rest is allocated without
                 struct Guard { std::vector<void*>& v; size_t& g; ~Guard() { for (void* q : v) (void)hipFree(q); v.clear(); g = 0; } } guard{throwaway, plain_gap};
                 plain_gap = gap;
                 arena = nullptr; arena_cap = 0; arena_used = 0; bytes = 0;
                 if ((rc = allocate_all())) return rc;
-                spread_gap_gib = (double)gap / (double)((size_t)1 << 30);
-                tries = 0;
+                spread_gap_gib = gap_log.empty() ? 0.0 : *std::min_element(gap_log.begin(), gap_log.end());
             }
         }
-        // Experiment / alternative: FDTD_PLACEMENT_SCAN_MB="0,256,512" makes ONE allocation with room for the
-        // largest offset, times the arena at each offset inside it (no free + allocate in between) and keeps
-        // the fastest.
-        std::vector<size_t> scan;
-        if (const char* e = getenv("FDTD_PLACEMENT_SCAN_MB")) {
-            for (const char* q = e; *q;) { char* end = nullptr; const long v = strtol(q, &end, 10); if (end == q) break; if (v >= 0) scan.push_back((size_t)v << 20); q = *end ? end + 1 : end; }
-        }
-        if (!scan.empty() && !vm_base) {
-            const size_t slack = *std::max_element(scan.begin(), scan.end());
-            char* base = nullptr;
-            FDTD_HIP(hipMalloc((void**)&base, arena_cap + slack));
-            allocs.push_back(base);
-            size_t best_off = scan[0];
-            double best_ms = 1e300;
-            for (size_t off : scan) {
-                arena = base + off; arena_used = 0; bytes = 0;
-                if ((rc = allocate_all())) return rc;
-                double ms = 0;
-                if ((rc = probe(&ms))) return rc;
-                placement_log.push_back(ms);
-                if (getenv("FDTD_PLACEMENT_DEBUG")) fprintf(stderr, "[fdtd] arena at %p + %zu MB: %.3f ms/step\n", (void*)base, off >> 20, ms);
-                if (ms < best_ms) { best_ms = ms; best_off = off; }
-            }
-            arena = base + best_off; arena_used = 0; bytes = 0;
-            if ((rc = allocate_all())) return rc;
-            tries = 0;
-        }
-        // Experiment: FDTD_NO_ARENA=1 gives every array a device allocation of its own (no common arena, no search)
-        if (const char* e = getenv("FDTD_NO_ARENA")) if (e[0] == '1' && scan.empty() && !vm_base) {
-            arena = nullptr; arena_cap = 0; arena_used = 0; bytes = 0;
-            if ((rc = allocate_all())) return rc;
-            double ms = 0;
-            if (getenv("FDTD_PLACEMENT_DEBUG") && !(rc = probe(&ms))) placement_log.push_back(ms);
-            if (rc) return rc;
-            tries = 0;
-        }
-        double best = 1e300, worst = 0;
-        for (int t = 0; tries > 0; ++t) {
+        if (!vm_base && allocs.empty()) {          // one plain allocation
             arena_used = 0; bytes = 0;
             FDTD_HIP(hipMalloc((void**)&arena, arena_cap));
             allocs.push_back(arena);
             if ((rc = allocate_all())) return rc;
-            if (tries <= 1) break;
-            double ms = 0;
-            if ((rc = probe(&ms))) return rc;
-            const bool explored = t + 1 >= explore || t + 1 >= tries;
-            best = std::min(best, ms); worst = std::max(worst, ms);
-            placement_log.push_back(ms);
-            if ((explored && ms <= std::max(best * 1.005, best + 0.2 * (worst - best))) || t + 1 >= tries) break;
-            FDTD_HIP(hipFree(arena));
-            allocs.clear(); arena = nullptr;
         }
         flips = 0;
-        if (getenv("FDTD_PLACEMENT_DEBUG")) { fprintf(stderr, "[fdtd] placement probes (ms/step):"); for (double v : placement_log) fprintf(stderr, " %.3f", v); fprintf(stderr, "\n"); }
         tab_h.assign((size_t)3 * 2 * 6 * kMaxLayers, 0.0);
         wf.assign(d.n_wf > 0 ? d.n_wf : 0, (T)0);
         return upload_tables();
@@ -1197,6 +1109,7 @@ struct Engine3 : fdtd3d_engine {
         return d.has_mu ? launch(k3_half_h<T, true, true>, a, kl0, kl1, 1, s, part) : launch(k3_half_h<T, false, true>, a, kl0, kl1, 1, s, part);
     }
     int half_e(int n, int part, hipStream_t s) override {
+        if (pair_phase != 0) return fail(FDTD_ERR_STATE, "half_e: a two-step launch is half done (EDGE without INTERIOR)");
         K3<T> a = args();
         a.src_on = (n >= 0 && n < (int)wf.size()) ? 1 : 0;
         a.jx = a.src_on ? a.dt * wf[n] : (T)0;      // product formed first, as FDTD3D.cpp:482
@@ -1205,6 +1118,7 @@ struct Engine3 : fdtd3d_engine {
         return launch_e(a, kl0, kl1, s, part);
     }
     int half_h(int part, hipStream_t s) override {
+        if (pair_phase != 0) return fail(FDTD_ERR_STATE, "half_h: a two-step launch is half done (EDGE without INTERIOR)");
         K3<T> a = args();
         int kl0, kl1;
         if (part == FDTD3D_PART_INTERIOR) {
@@ -1308,6 +1222,7 @@ struct Engine3 : fdtd3d_engine {
     }
     int fused_part(int n, int part, hipStream_t s) override {
         if (!fused) return fail(FDTD_ERR_STATE, "fused stepping needs an engine created with FDTD3D_MODE_FUSED");
+        if (pair_phase != 0) return fail(FDTD_ERR_STATE, "fused: a two-step launch is half done (EDGE without INTERIOR)");
         // EDGE only has to produce layer z_lo early, TOP only the top layer: these launches have too few
         // workgroups to fill the chip, so they take as few planes as possible and leave the rest to INTERIOR
         const int lo = 1, hi = last_rank ? nzp : nzp - 1, few = std::min(chunk, edge_planes);
@@ -1349,6 +1264,7 @@ struct Engine3 : fdtd3d_engine {
         if (!fused || d.z_lo != 0 || d.z_hi != d.Nz || pair_off) return false;
         for (int m = 0; m < 2; ++m) for (int c = 0; c < 3; ++c) for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd)
             if (phSize[m][c][ax][sd] >= ((size_t)1 << 31)) return false;       // the kernel indexes the CPML state with 32 bits
+        if (!pair_scratch_ok()) return false;
         if (const char* e = getenv("FDTD_PAIR")) return atoi(e) != 0;
         bool pml = false;
         for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) pml = pml || np[ax][sd] != 0;
@@ -1413,10 +1329,9 @@ struct Engine3 : fdtd3d_engine {
     int pair_remap(const PairTiles& t) const { return remap == kRemapAuto ? (t.wrap_l > 0 ? t.nbx : 0) : remap; }
     void pair_layout(int out[4]) override { const PairTiles t = pair_tiles(); out[0] = t.nbx; out[1] = t.wrap_l; out[2] = t.wrap_r0; out[3] = pair_remap(t); }
     int step_pair(int n, hipStream_t s) override { return step_pair_part(n, FDTD3D_PART_ALL, s); }
-    // One launch of the two-step kernel over the owned planes [r0, r1).
-    int pair_launch(K3<T> a, int r0, int r1, int part, bool pml, hipStream_t s) {
-        if (r1 <= r0) return FDTD_OK;
-        constexpr int PV = V / 2, TW = kLanes * PV;
+    // Cuts the planes [r0, r1) of a two-step launch into chunks; returns the number of workgroups (a.nbx, a.nby and
+    // a.chunk must be set).
+    unsigned pair_plan(K3<T>& a, int r0, int r1) const {
         a.kl0 = r0; a.kl1 = r1;
         // chunks that come near the z layers (within the four planes a chunk looks below itself, the one above) are cut
         // separately: everything else then runs the loop without z-layer code.  Local plane = global plane - zoff.
@@ -1430,9 +1345,27 @@ struct Engine3 : fdtd3d_engine {
         }
         a.znb[0] = nb[0]; a.znb[1] = nb[1];
         a.nbz = nb[0] + nb[1] + nb[2];
-        const unsigned nblk = (unsigned)a.nbx * a.nby * a.nbz;
+        return (unsigned)a.nbx * a.nby * a.nbz;
+    }
+    // whether a two-step launch over all owned planes stays within the scratch memory the kernel can address
+    bool pair_scratch_ok() const {
+        bool pml = false;
+        for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) pml = pml || np[ax][sd] != 0;
+        if (!pml) return true;
+        K3<T> a{};
+        a.nbx = pair_tiles().nbx; a.nby = (ny1 + (wpbp - 3) - 1) / (wpbp - 3); a.chunk = pair_chunk();
+        return fdtd3d_pair_scratch_fits((long long)pair_plan(a, 1, last_rank ? nzp : nzp - 1), wpbp, (int)sizeof(T) * 8) != 0;
+    }
+    // One launch of the two-step kernel over the owned planes [r0, r1).
+    int pair_launch(K3<T> a, int r0, int r1, int part, bool pml, hipStream_t s) {
+        if (r1 <= r0) return FDTD_OK;
+        constexpr int PV = V / 2, TW = kLanes * PV;
+        const unsigned nblk = pair_plan(a, r0, r1);
         const size_t lds = ((size_t)6 + (size_t)3 * 2 * wpbp * 2) * TW * sizeof(T);
         const size_t scr_need = pml ? (size_t)nblk * wpbp * 24 * TW : 0;
+        // the kernel forms a wave's offset into the scratch memory in 32 bits
+        if (!fdtd3d_pair_scratch_fits((long long)nblk, wpbp, (int)sizeof(T) * 8))
+            return fail(FDTD_ERR_STATE, "two-step launch: %u workgroups need %zu elements of scratch memory, the kernel addresses 2^32; use longer chunks (fdtd3d_pair_shape)", nblk, scr_need);
         if (scr_need > pair_scr_elems) {
             // (launches of one stream run one after the other, so the new piece can replace the old one for all of them;
             // the old piece stays with the engine until it is destroyed)
@@ -1455,6 +1388,7 @@ struct Engine3 : fdtd3d_engine {
     // bulk is computed: PART_EDGE = the three lowest and the three highest owned planes (the buffers change roles here, as
     // with fdtd3d_fused), PART_INTERIOR = the rest.
     int pair_phase = 0;
+    hipStream_t pair_stream = nullptr;
     static constexpr int kPairEdge = 3;
     int step_pair_part(int n, int part, hipStream_t s) override {
         if (!fused) return fail(FDTD_ERR_STATE, "two-step launches need an engine created with FDTD3D_MODE_FUSED");
@@ -1465,6 +1399,9 @@ struct Engine3 : fdtd3d_engine {
         if (phase != 0) return fail(FDTD_ERR_STATE, "two-step launch in the middle of a split step");
         if (part != FDTD3D_PART_ALL && part != FDTD3D_PART_EDGE && part != FDTD3D_PART_INTERIOR) return fail(FDTD_ERR_ARG, "two-step launch: bad part %d", part);
         if ((part == FDTD3D_PART_INTERIOR) != (pair_phase == 1)) return fail(FDTD_ERR_STATE, "two-step launches: a pair of steps is ALL, or EDGE then INTERIOR");
+        // all launches of an engine share one piece of scratch memory, indexed by workgroup: two of them must not run
+        // at the same time, so both parts of a pair go on one stream
+        if (part == FDTD3D_PART_INTERIOR && s != pair_stream) return fail(FDTD_ERR_STATE, "two-step launches: INTERIOR must be launched on the stream EDGE was launched on");
         K3<T> a = args();
         const bool s1 = n >= 0 && n < (int)wf.size(), s2 = n + 1 >= 0 && n + 1 < (int)wf.size();
         a.src_on = (s1 ? 1 : 0) | (s2 ? 2 : 0);
@@ -1506,6 +1443,7 @@ struct Engine3 : fdtd3d_engine {
             ++flips;
         }
         pair_phase = part == FDTD3D_PART_EDGE ? 1 : 0;
+        pair_stream = s;
         return FDTD_OK;
     }
 
@@ -1660,7 +1598,7 @@ int fdtd3d_probe_add(fdtd3d_handle h, int id, int i, int j, int k) { return entr
 int fdtd3d_probe_record(fdtd3d_handle h, void* stream) { return entry(h, [&] { return h->probe_record((hipStream_t)stream); }); }
 int fdtd3d_probe_read(fdtd3d_handle h, double* out, size_t cap, int* n_samples, int* n_probes) { return entry(h, [&] { return h->probe_read(out, cap, n_samples, n_probes); }); }
 int fdtd3d_probe_reset(fdtd3d_handle h, int drop_probes) { return entry(h, [&] { return h->probe_reset(drop_probes); }); }
-int fdtd3d_placement_probes(fdtd3d_handle h, double* ms, int cap) { return (h && (ms || cap == 0)) ? h->placement(ms, cap) : 0; }
+int fdtd3d_spread_gaps(fdtd3d_handle h, double* gib, int cap) { return (h && (gib || cap == 0)) ? h->gaps(gib, cap) : 0; }
 int fdtd3d_buffer_parity(fdtd3d_handle h) { return h ? h->parity() : 0; }
 int fdtd3d_half_e(fdtd3d_handle h, int n, int part, void* stream) { return entry(h, [&] { return h->half_e(n, part, (hipStream_t)stream); }); }
 int fdtd3d_half_h(fdtd3d_handle h, int part, void* stream) { return entry(h, [&] { return h->half_h(part, (hipStream_t)stream); }); }

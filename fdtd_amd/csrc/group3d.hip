@@ -7,6 +7,7 @@
 
 #include <cstdlib>
 #include <memory>
+#include <unordered_map>
 #include <utility>
 
 using namespace fdtd;
@@ -32,11 +33,11 @@ struct fdtd3d_group {
     // The slab every stream and event was created for, so that record() can refuse a pair that would
     // sit on different devices on a multi-GPU node -- also when all slabs share one device, where HIP
     // itself would accept it.
-    std::vector<std::pair<void*, int>> owner;
+    std::unordered_map<void*, int> owner;
     long records_checked = 0;
     int owner_of(void* handle) const {
-        for (const auto& o : owner) if (o.first == handle) return o.second;
-        return -1;
+        const auto it = owner.find(handle);
+        return it == owner.end() ? -1 : it->second;
     }
 
     ~fdtd3d_group() {
@@ -54,6 +55,8 @@ struct fdtd3d_group {
 };
 
 namespace {
+
+bool g_misown_events = false;       // see fdtd3d_group_debug_misown_events
 
 // hipEventRecord with the ownership rule enforced: event and stream must have been created for the
 // same slab (hence on the same device).
@@ -205,22 +208,21 @@ int build_group(fdtd3d_group* g, const fdtd3d_desc* desc, int n_slabs, const int
     const size_t R = (size_t)n_slabs;
     g->run.assign(R, nullptr); g->up.assign(R, nullptr); g->down.assign(R, nullptr);
     g->edge_done.assign(R, nullptr); g->top_done.assign(R, nullptr); g->sent_down.assign(R, nullptr); g->sent_up.assign(R, nullptr);
-    // FDTD_GROUP_MISOWN_EVENTS=1 (tests only) files the two arrival events under the RECEIVING slab, the
-    // mistake the ownership rule exists to catch: the first step of such a group must be refused.
-    const char* mis = getenv("FDTD_GROUP_MISOWN_EVENTS");
-    const bool misown = mis && mis[0] == '1';
+    // (tests only, fdtd3d_group_debug_misown_events) the two arrival events filed under the RECEIVING slab, the
+    // mistake the ownership rule exists to catch: the first step of such a group must be refused
+    const bool misown = g_misown_events;
     for (size_t r = 0; r < R; ++r) {
         DeviceScope scope(g->device[r]);
         for (auto* v : {&g->run, &g->up, &g->down}) {
             FDTD_HIP(hipStreamCreate(&(*v)[r]));
-            g->owner.emplace_back((void*)(*v)[r], (int)r);
+            g->owner[(void*)(*v)[r]] = (int)r;
         }
         for (auto* v : {&g->edge_done, &g->top_done, &g->sent_down, &g->sent_up}) {
             FDTD_HIP(hipEventCreateWithFlags(&(*v)[r], hipEventDisableTiming));
             int own = (int)r;
             if (misown && v == &g->sent_down && r > 0) own = (int)r - 1;
             if (misown && v == &g->sent_up && r + 1 < R) own = (int)r + 1;
-            g->owner.emplace_back((void*)(*v)[r], own);
+            g->owner[(void*)(*v)[r]] = own;
         }
     }
     return FDTD_OK;
@@ -261,7 +263,10 @@ int fdtd3d_group_destroy(fdtd3d_group_handle g) {
 }
 
 int fdtd3d_group_slabs(fdtd3d_group_handle g) { return g ? (int)g->member.size() : 0; }
+// Test hooks, deliberately absent from the public header: how many event records have passed the ownership check,
+// and a switch that makes groups created afterwards file their arrival events under the wrong slab.
 long fdtd3d_group_records_checked(fdtd3d_group_handle g) { return g ? g->records_checked : 0; }
+void fdtd3d_group_debug_misown_events(int on) { g_misown_events = on != 0; }
 
 fdtd3d_handle fdtd3d_group_member(fdtd3d_group_handle g, int r) {
     return (g && r >= 0 && r < (int)g->member.size()) ? g->member[r] : nullptr;

@@ -249,11 +249,11 @@ class Engine3D(_Common):
         """Finish B of the top owned layer after the upper neighbour's D has arrived (no-op on the last slab)."""
         _check(lib().fdtd3d_fused_top(self.h, _stream_handle(stream)), "fdtd3d_fused_top")
 
-    def placement_probes(self):
-        """Step times (ms) of the device-memory placements tried at creation (empty for small engines)."""
-        buf = (C.c_double * 16)()
-        n = lib().fdtd3d_placement_probes(self.h, buf, C.c_int(16))
-        return [buf[i] for i in range(min(n, 16))]
+    def spread_gaps(self):
+        """GiB of physical memory left out in front of every large array but the first (empty: one plain allocation)."""
+        buf = (C.c_double * 64)()
+        n = lib().fdtd3d_spread_gaps(self.h, buf, C.c_int(64))
+        return [buf[i] for i in range(min(n, 64))]
 
     def kernel_timeline(self):
         """[(kind, part, start_ms, duration_ms)] of the launches timed since the last kernel_time() of their kind."""

@@ -82,7 +82,12 @@ typedef struct fdtd3d_desc {
     int32_t n_pml[6];         /* xn, xp, yn, yp, zn, zp (FDTD3D.h:54-56)                    */
     int32_t k_Jx;             /* source plane (FDTD3D.h:106)                                 */
     int32_t n_wf;             /* waveform length (m_steps)                                   */
-    int32_t precision;        /* 32 or 64                                                    */
+    int32_t precision;        /* 32 or 64.  64 is the mode that matches the reference: bit for bit, over its whole
+                                 run lengths.  32 equals an fp32 restatement of the reference's loops bit for bit and
+                                 stays within 1e-6 relative L2 of the fp64 reference for a limited number of steps
+                                 (measured: about 700 on the 3-D default problem, where the drift grows as
+                                 4e-8*sqrt(steps); about 20 for H in a lossless cavity, 600 for E; about 150 on the
+                                 2-D default problem, whose undamped Lorentz recursion makes it grow quadratically) */
     int32_t has_mu;           /* 0: H = B/mu0 (reference), 1: H = B/mu_{x,y,z}               */
     int32_t mode;             /* FDTD3D_MODE_*                                               */
     int32_t z_lo, z_hi;       /* owned cell layers [z_lo, z_hi); 0,Nz = whole grid           */
@@ -162,6 +167,12 @@ int fdtd3d_planes(fdtd3d_handle h, int id, int k, int count, void** p, size_t* b
  * launches; the buffers change roles here, as with fdtd3d_fused, so fdtd3d_planes already refers to the new
  * values), then FDTD3D_PART_INTERIOR = the rest.  FDTD3D_PART_ALL = fdtd3d_step_pairs(h, n, 1, stream). */
 int fdtd3d_pair_part(fdtd3d_handle h, int n, int part, void* stream);
+/* Both parts of a pair must be launched on the same stream (all launches of an engine share one piece of scratch
+ * memory); between EDGE and INTERIOR every other stepping call on the engine is refused with FDTD_ERR_STATE.
+ * 1 if a two-step launch of `workgroups` workgroups of `waves_per_group` waves stays within the scratch memory the
+ * kernel can address (it forms a wave's offset in 32 bits: 24 row segments per wave, below 2^32 elements in all), else
+ * 0; launches beyond it are refused with FDTD_ERR_STATE, and fdtd3d_step then takes single steps.  Needs no device. */
+int fdtd3d_pair_scratch_fits(long long workgroups, int waves_per_group, int precision_bits);
 /* out = { 1 if fdtd3d_step takes its steps two per launch on this engine, planes per workgroup,
  *         waves per workgroup, elements per lane } of the two-step kernel. */
 int fdtd3d_pair_info(fdtd3d_handle h, int out[4]);
@@ -257,28 +268,25 @@ int fdtd3d_probe_record(fdtd3d_handle h, void* stream);
 int fdtd3d_probe_read(fdtd3d_handle h, double* out, size_t cap, int* n_samples, int* n_probes);
 int fdtd3d_probe_reset(fdtd3d_handle h, int drop_probes);
 
-/* Placement of large engines (>= 8 GiB of device state).  The step kernels stream from all field arrays at once, and
- * the rate depends on how far apart those arrays lie in physical device memory: adjacent is slowest, a few GiB of other
- * memory between two arrays fastest (1024^3 fused step: 17.8 ms adjacent, 16.7 ms with 6 GiB between arrays).
- * An engine that holds a whole grid (of 2 GiB or more) therefore backs its arrays through the virtual-memory API with
+/* Placement of large engines (2 GiB of device state or more).  The step kernels stream from all field arrays at once,
+ * and the rate depends on how far apart those arrays lie in physical device memory: adjacent is slowest, about 10 GiB of
+ * other memory between two arrays fastest (1024^3, two steps per launch: 11.85 ms per step with 4 GiB between the arrays,
+ * 11.12 with 10).  An engine that holds a whole grid therefore backs its arrays through the virtual-memory API with
  * physical chunks created in order, and creates and releases up to 10 GiB of further chunks in front of every field array:
- * the arrays end up that far apart physically while the process only holds their own memory.  A slab engine (of 2 GiB or
- * more) reaches the same layout with ordinary allocations -- every array a hipMalloc of its own, each large one behind a
- * throw-away allocation of the gap, all of which are freed once the arrays exist -- because its planes travel between
- * devices.  fdtd3d_spread_gap_gib() reports the gap used (0 if the arrays lie side by side).  Environment: FDTD_SPREAD=0
- * off, FDTD_SPREAD=1 the virtual-memory way also for slab engines and small ones, FDTD_SPREAD_GAP_MB / FDTD_SLAB_GAP_MB
- * the gap.  Memory backed this way must be opened to another device before that device can copy
- * to or from it: fdtd3d_grant_peer_access() (the slab group does it for neighbouring slabs). */
+ * the arrays end up that far apart physically while the process only holds their own memory.  A slab engine reaches the
+ * same layout with ordinary allocations -- every array a hipMalloc of its own, each large one behind a throw-away
+ * allocation of the gap, all of which are freed once the arrays exist -- because its planes travel between devices.  Both
+ * take less where less is free, and fall back to one plain allocation when no useful gap is left (a slab engine whose
+ * gaps leave no room for an array gives them back at once and goes on without).  While an engine is being created it
+ * transiently holds that extra memory: two engines created at the same moment on one device can fail for lack of it.
+ * fdtd3d_spread_gap_gib() reports the smallest gap achieved (0: the arrays lie side by side), fdtd3d_spread_gaps() the
+ * gap in front of every large array but the first, in allocation order (returns their number, copies up to `cap`).
+ * Environment: FDTD_SPREAD=0 off, FDTD_SPREAD=1 the virtual-memory way for every engine, FDTD_SPREAD_GAP_MB the gap.
+ * Memory backed through the virtual-memory API must be opened to another device before that device can copy to or from
+ * it: fdtd3d_grant_peer_access() (the slab group does it for neighbouring slabs). */
 double fdtd3d_spread_gap_gib(fdtd3d_handle h);
+int fdtd3d_spread_gaps(fdtd3d_handle h, double* gib, int cap);
 int fdtd3d_grant_peer_access(fdtd3d_handle h, int peer_device);
-
-/* Large engines whose arrays share one allocation (FDTD_SPREAD=0, or FDTD_SLAB_GAP_MB=0 for slabs) are placed in device
- * memory up to FDTD_PLACEMENT_TRIES times (environment, default 8, 1 = off) at creation: where the driver puts a large allocation
- * changes the streaming rate of the step kernels by several percent, so each placement is timed with
- * a few source-free steps on the zero state and, after five, the first one in the fast fifth of the
- * range seen is kept.
- * Returns how many placements were timed and copies up to `cap` of their step times (ms). */
-int fdtd3d_placement_probes(fdtd3d_handle h, double* ms_per_step, int cap);
 
 /* Bytes of device memory held by the handle. */
 size_t fdtd3d_device_bytes(fdtd3d_handle h);
@@ -328,9 +336,7 @@ int fdtd3d_group_destroy(fdtd3d_group_handle g);
 int fdtd3d_group_slabs(fdtd3d_group_handle g);
 /* Every event of a group is recorded through a check that event and stream were created for the same
  * slab (HIP refuses to record an event on a stream of another device; with all slabs on one device
- * it would not notice).  A mismatch makes fdtd3d_group_step() fail with FDTD_ERR_STATE; this returns
- * how many records have passed the check so far. */
-long fdtd3d_group_records_checked(fdtd3d_group_handle g);
+ * it would not notice).  A mismatch makes fdtd3d_group_step() fail with FDTD_ERR_STATE. */
 fdtd3d_handle fdtd3d_group_member(fdtd3d_group_handle g, int r);
 int fdtd3d_group_step(fdtd3d_group_handle g, int n0, int count);
 int fdtd3d_group_sync(fdtd3d_group_handle g);
@@ -370,7 +376,8 @@ typedef struct fdtd2d_desc {
     int32_t n_pml[4];         /* xn, xp, zn, zp (FDTD2D.h:41) */
     int32_t i_Jy, k_Jy;       /* source cell (FDTD2D.h:62) */
     int32_t n_wf;
-    int32_t precision;        /* 32 or 64 */
+    int32_t precision;        /* 32 or 64; 64 matches the reference bit for bit, 32 holds 1e-6 for about 150 steps
+                                 on the default problem (see fdtd3d_desc) */
     int32_t device;
     double dx, dz, dt;
     double mu0, eps0;         /* FDTD2D.h:19-20 */

@@ -90,7 +90,7 @@ def test_single_process_group_mode_equals_one(mode):
     """`bench.py --gpus N` started as a plain process: one host thread drives N slabs through a slab group
     (here all on cuda:0).  Same grid, same checksum, same JSON keys."""
     one = _bench({"FDTD_BENCH_MODE": mode}, 1)
-    env = dict(os.environ, FDTD_BENCH_N="192", FDTD_BENCH_NZ="384", FDTD_BENCH_ONE_DEVICE="1", FDTD_BENCH_MODE=mode)
+    env = dict(os.environ, FDTD_BENCH_N="192", FDTD_BENCH_NZ="384", FDTD_BENCH_ONE_DEVICE="1", FDTD_BENCH_MODE=mode, FDTD_BENCH_GROUP="1")
     for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(key, None)
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "3", "--steps", "7", "--warmup", "2"], cwd=ROOT, env=env,
@@ -104,6 +104,43 @@ def test_single_process_group_mode_equals_one(mode):
     for key in ("metric", "value", "unit", "ms_per_step", "roofline", "scaling", "dtype", "config"):
         assert key in many
     _check_multi_gpu_block(many, 3, mode, "one host thread")
+
+
+def test_plain_start_with_several_gpus_takes_two_steps_per_launch():
+    """`python bench.py --gpus 2` without a launcher: the program starts the launcher form as a child process before
+    it touches a GPU and relays the child's line -- one process per GPU, overlapping slabs, two steps per launch --
+    instead of falling back to the one-step kernels of the single-process slab group."""
+    one = _bench({}, 1)
+    env = dict(os.environ, FDTD_BENCH_N="192", FDTD_BENCH_NZ="384", FDTD_BENCH_CPU="0", FDTD_BENCH_ONE_DEVICE="1")
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FDTD_BENCH_GROUP", "FDTD_BENCH_BACKEND"):
+        env.pop(key, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "7", "--warmup", "2"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]        # stdout carries the one JSON line only
+    many = json.loads(lines[0])
+    assert many["n_gpus"] == 2 and many["steps"] == 7 and many["warmup"] == 2
+    assert many["roofline"]["kernel"] == "k3_pair" and many["roofline"]["steps_per_launch"] == 2
+    assert many["checks"]["checksum_dx"] == one["checks"]["checksum_dx"]
+    assert "child" in many["config"]["launched_as"]
+    _check_multi_gpu_block(many, 2, "fused", "gloo")
+
+
+def test_secondary_legs_ride_on_the_one_line():
+    """N = 1: after the headline engine has been released the same program times the fp64 twin of the headline
+    configuration, the vacuum cavity and the 2-D grid (here at test sizes) and reports them under `extra`."""
+    line = _bench({"FDTD_BENCH_EXTRA": "small"}, 1)
+    extra = line["extra"]
+    assert set(extra) == {"fp64_small", "cavity_small", "fdtd2d_small", "fdtd2d_small_dispersive_everywhere"}
+    for name, leg in extra.items():
+        assert "error" not in leg, (name, leg)
+        assert leg["ms_per_step"] > 0 and leg["value"] > 0 and leg["checks"]["finite"]
+        assert 0 < leg["roofline"]["frac"] and leg["kernel_ms_per_step"] > 0
+    assert extra["fp64_small"]["dtype"] == "f64" and extra["fp64_small"]["checks"]["sumsq_dx"] > 0
+    assert extra["cavity_small"]["checks"]["sumsq_dx"] > 0
+    assert extra["fdtd2d_small_dispersive_everywhere"]["dispersive_cells"] == 512 * 512
+    assert 0 < extra["fdtd2d_small"]["dispersive_cells"] < 512 * 512
 
 
 def test_rccl_self_exchange_on_engine_memory():

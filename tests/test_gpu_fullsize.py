@@ -107,14 +107,10 @@ def test_fused_equals_lean_1024_headline_workload():
     lean.close()
     assert e_lean > 0 and np.isfinite(e_lean)
     fused = make(N, (20,) * 6, E.MODE_FUSED, True, steps=steps)
-    # an engine this large either spreads its field arrays over physical memory (whole grids, the default) or times a
-    # few placements of one allocation at creation (slab engines, FDTD_SPREAD=0)
-    probes = fused.placement_probes()
-    if fused.spread_gap_gib() > 0:
-        assert len(probes) <= 1
-    else:
-        assert 3 <= len(probes) <= 8 and all(5.0 < ms < 100.0 for ms in probes)
-        assert probes[-1] <= min(probes) + 0.36 * (max(probes) - min(probes)) + 0.01 or len(probes) == 8
+    # an engine this large spreads its field arrays over physical memory: one gap in front of every large array but
+    # the first (D, B twice each, eps, mu: 18 arrays), the smallest of them reported as the engine's gap
+    gaps = fused.spread_gaps()
+    assert len(gaps) == 17 and min(gaps) == fused.spread_gap_gib() and fused.spread_gap_gib() > 0
     fused.step(0, 4)
     fused.tune(5, 0, 8)
     fused.step(4, steps - 4)
@@ -122,15 +118,21 @@ def test_fused_equals_lean_1024_headline_workload():
     fused.close()
 
 
-def test_placement_search_when_spreading_is_off(monkeypatch):
-    """FDTD_SPREAD=0: one plain allocation, placed up to eight times and timed (the path slab engines take)."""
-    monkeypatch.setenv("FDTD_SPREAD", "0")
-    eng = make((1024, 1024, 256), (20,) * 6, E.MODE_FUSED, True, steps=4)      # 21 GB: large enough to be searched
-    probes = eng.placement_probes()
-    assert eng.spread_gap_gib() == 0 and 3 <= len(probes) <= 8 and all(1.0 < ms < 50.0 for ms in probes)
-    eng.step(0, 3)
-    assert np.isfinite(eng.sumsq(E.DX))
-    eng.close()
+def test_plain_allocation_when_spreading_is_off(monkeypatch):
+    """FDTD_SPREAD=0: one plain allocation, same bits as the spread engine."""
+    want = None
+    for spread in ("0", None):
+        if spread is None:
+            monkeypatch.delenv("FDTD_SPREAD")
+        else:
+            monkeypatch.setenv("FDTD_SPREAD", spread)
+        eng = make((1024, 1024, 256), (20,) * 6, E.MODE_FUSED, True, steps=4)      # 21 GB
+        assert (eng.spread_gap_gib() == 0 and eng.spread_gaps() == []) if spread == "0" else eng.spread_gap_gib() > 0
+        eng.step(0, 3)
+        got = [eng.checksum(i) for i in FIELDS]
+        assert np.isfinite(eng.sumsq(E.DX)) and (want is None or got == want)
+        want = got
+        eng.close()
 
 
 def test_fused_slabs_equal_whole_grid_384():

@@ -176,10 +176,13 @@ def test_group_events_are_recorded_on_streams_of_their_own_slab(monkeypatch):
         # per step: edge_done and top_done on each of 3 slabs, one arrival event per direction and interface
         assert L.fdtd3d_group_records_checked(g.h) == 2 * (3 + 3 + 2 + 2)
         g.close()
-    monkeypatch.setenv("FDTD_GROUP_MISOWN_EVENTS", "1")
-    for mode in (E.MODE_FUSED, E.MODE_LEAN):
-        g = group_from_meta(meta, 32, 3, mode)
-        util.feed(g, ins)
-        with pytest.raises(E.EngineError, match="recorded on a stream of slab"):
-            g.step(0, 1)
-        g.close()
+    L.fdtd3d_group_debug_misown_events(1)          # a test hook of the library, not part of the public header
+    try:
+        for mode in (E.MODE_FUSED, E.MODE_LEAN):
+            g = group_from_meta(meta, 32, 3, mode)
+            util.feed(g, ins)
+            with pytest.raises(E.EngineError, match="recorded on a stream of slab"):
+                g.step(0, 1)
+            g.close()
+    finally:
+        L.fdtd3d_group_debug_misown_events(0)

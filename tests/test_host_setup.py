@@ -96,3 +96,18 @@ def test_group_and_device_count_refuse_without_touching_a_device():
         assert n == (torch.cuda.device_count() if torch.cuda.is_available() else 0)
     except ImportError:
         assert n >= 0
+
+
+def test_pair_scratch_bound_is_checked_on_the_host():
+    """The two-step kernel forms a wave's offset into its CPML scratch memory in 32 bits: 24 row segments of a
+    wave's columns (128 in fp32, 64 in fp64) per wave.  The headline launch (1024^3, 128 planes per workgroup)
+    fits; the same grid cut into 8-plane chunks would need 4.5e9 elements and must be refused, not wrapped."""
+    L = fdtd_amd.lib()
+    L.fdtd3d_pair_scratch_fits.argtypes = [C.c_longlong, C.c_int, C.c_int]
+    per_group32 = 16 * 24 * 128
+    assert L.fdtd3d_pair_scratch_fits(9 * 79 * 10, 16, 32) == 1                 # 1024^3, default shape: 0.35e9 elements
+    assert L.fdtd3d_pair_scratch_fits(92_000, 16, 32) == 0                      # 1024^3 in 8-plane chunks: 4.5e9
+    edge = (2 ** 32 - 1) // per_group32
+    assert L.fdtd3d_pair_scratch_fits(edge, 16, 32) == 1 and L.fdtd3d_pair_scratch_fits(edge + 1, 16, 32) == 0
+    assert L.fdtd3d_pair_scratch_fits(2 * edge, 16, 64) == 1 and L.fdtd3d_pair_scratch_fits(2 * edge + 2, 16, 64) == 0
+    assert L.fdtd3d_pair_scratch_fits(10, 16, 16) == 0 and L.fdtd3d_pair_scratch_fits(-1, 16, 32) == 0

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Is the step time independent of the data?  The headline workload (1024^3, eps/mu grids, 20-layer CPML,
-fp32, fused kernel) timed (a) from the cold start, where after 30 steps nearly every cell still holds zero,
+fp32, fused storage: two steps per launch unless FDTD_PAIR=0) timed (a) from the cold start, where after 30 steps nearly every cell still holds zero,
 (b) after the wave of the sheet source has crossed a good part of the grid, (c) with D and B filled with
 noise at every cell.  The kernels have no data-dependent branch; this shows it.
     python tools/bench_data.py [edge]"""
@@ -36,12 +36,13 @@ def timed(n0, count=20):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     eng.kernel_timing(False)
-    nl, ms = eng.kernel_time(2)
-    return el / count * 1e3, ms / max(nl, 1)
+    n1, ms1 = eng.kernel_time(2)          # one step per launch
+    n2, ms2 = eng.kernel_time(3)          # two steps per launch
+    return el / count * 1e3, (ms1 + ms2) / max(n1 + 2 * n2, 1)
 
 
-print(f"placement probes {[round(v, 2) for v in eng.placement_probes()]}")
-print("| state | steps done | wall ms/step | kernel ms/launch | sum Dx^2 |\n|---|---|---|---|---|")
+print(f"gaps GiB {[round(v, 2) for v in eng.spread_gaps()]}")
+print("| state | steps done | wall ms/step | kernel ms/step | sum Dx^2 |\n|---|---|---|---|---|")
 eng.step(0, 10)
 done = 10
 w, k = timed(done); done += 20

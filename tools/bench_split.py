@@ -64,4 +64,4 @@ for name, fn in (("one launch", one), ("split", split), ("one launch", one), ("s
     nf, msf = eng.kernel_time(2)
     nh, msh = eng.kernel_time(1)
     print(f"{name:10s}: {el / steps * 1e3:7.3f} ms/step wall; fused launches {nf / steps:.0f}/step {msf / steps:7.3f} ms, "
-          f"top-layer kernel {msh / steps:6.3f} ms; placements {[round(v, 2) for v in eng.placement_probes()]}", flush=True)
+          f"top-layer kernel {msh / steps:6.3f} ms; gaps GiB {[round(v, 2) for v in eng.spread_gaps()]}", flush=True)

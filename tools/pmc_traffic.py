@@ -53,7 +53,7 @@ def main():
     from fdtd_amd.engine import kernel_source_digest
     work = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
     shape_file = os.path.join(work, "shape.json")
-    env = dict(os.environ, TMPDIR="/tmp", FDTD_SHAPE_OUT=shape_file, FDTD_PLACEMENT_TRIES="1")
+    env = dict(os.environ, TMPDIR="/tmp", FDTD_SHAPE_OUT=shape_file)
     fetch = one_pass("FETCH_SIZE", prog, work, env)
     write = one_pass("WRITE_SIZE", prog, work, env)
     keep = [k for k in args.kernels.split(",") if k]

@@ -22,7 +22,7 @@ wf, mag = fs.default_source3d(n, n, 4096, d, dt)
 eng.set(E.JX_WF, wf)
 eng.set(E.JX_MAG, mag)
 eng.fill_materials(1234, K["eps0"], 4 * K["eps0"], K["mu0"], 2 * K["mu0"])
-print("gap GiB", eng.spread_gap_gib(), "probes", eng.placement_probes(), flush=True)
+print("gap GiB", eng.spread_gap_gib(), "gaps", eng.spread_gaps(), flush=True)
 step = [0]
 
 
