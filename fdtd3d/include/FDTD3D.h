@@ -24,12 +24,13 @@ struct Sim3DConfig {
     int n_T0;              // steps per optical period: RMS window = n_T0/2, weights 4/n_T0
     int frame_every;
     bool write_files;
+    bool step_by_step;     // one engine call per step, as the reference's loop is written (for comparison: the engine then cannot take two steps per launch)
     bool binary_vti;       // opt-in: raw appended Float32 VTI instead of the reference's ASCII Float64
     std::string out_dir;
     // The reference's hard-coded problem (FDTD3D.cpp:21-39, :71, FDTD3D.h:54-56).
     static Sim3DConfig reference_default();
     // Overrides from FDTD3D_NX / _NY / _NZ / _STEPS / _NPML / _KJX / _PRECISION / _LEAN / _FUSED / _SLABS / _FRAME_EVERY / _BINARY_VTI /
-    // _WRITE / _OUT environment variables (the reference's main() takes no arguments).
+    // _WRITE / _STEP_BY_STEP / _OUT environment variables (the reference's main() takes no arguments).
     void apply_environment();
 };
 
@@ -44,7 +45,8 @@ public:
     void run();
 
     const Sim3DConfig& config() const { return m_cfg; }
-    double seconds_in_steps() const { return m_step_seconds; }
+    double seconds_in_steps() const { return m_step_seconds; }          // time loop incl. downloads and file output
+    double seconds_on_device() const { return m_device_seconds; }       // stepping + RMS window on the device only
 
 private:
     void build();
@@ -54,5 +56,5 @@ private:
     fdtd3d_group* m_group = nullptr;   // the slabs of the grid (a single one by default)
     std::unique_ptr<FieldWriter3D> m_out;
     std::vector<double> m_a, m_b;     // download buffers, [Nz][Ny][Nx]
-    double m_step_seconds = 0.0;
+    double m_step_seconds = 0.0, m_device_seconds = 0.0;
 };

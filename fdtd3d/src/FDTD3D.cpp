@@ -49,6 +49,7 @@ Sim3DConfig Sim3DConfig::reference_default() {
     c.n_T0 = static_cast<int>(std::round(2 * cells_per_wavelength));
     c.frame_every = 20;
     c.write_files = true;
+    c.step_by_step = false;
     c.out_dir = "output_3d";
     return c;
 }
@@ -63,6 +64,7 @@ void Sim3DConfig::apply_environment() {
     if (env_int("FDTD3D_FUSED", v)) fused = v != 0;
     env_int("FDTD3D_SLABS", slabs);
     if (env_int("FDTD3D_WRITE", v)) write_files = v != 0;
+    if (env_int("FDTD3D_STEP_BY_STEP", v)) step_by_step = v != 0;
     if (env_int("FDTD3D_BINARY_VTI", v)) binary_vti = v != 0;
     if (const char* e = std::getenv("FDTD3D_OUT")) if (*e) out_dir = e;
 }
@@ -135,18 +137,30 @@ void FDTD3D::run() {
     const Sim3DConfig& c = m_cfg;
     const int half_period = c.n_T0 / 2;
     const double weight = 4.0 / c.n_T0;
-    for (int n = 0; n < c.steps; ++n) {
+    // The reference looks at the fields after every step (FDTD3D.cpp:1085-1108): the RMS window is advanced, a completed
+    // window written out, every frame_every-th step dumped.  Here the steps between two of those moments go to the engine
+    // in one call, which advances the window on the device by itself (two steps per launch on large grids).  A run of
+    // steps ends at the next step whose fields are dumped, and one step after the next step that completes a window at
+    // the latest -- the engine keeps a completed window until the next one completes, so the step that follows it may
+    // still ride in the same launch.
+    const int every = c.frame_every > 0 ? c.frame_every : c.steps + 1;
+    for (int n = 0; n < c.steps;) {
         const auto t0 = std::chrono::steady_clock::now();
-        must(fdtd3d_group_step(m_group, n, 1), "step");
-        must(fdtd3d_group_observe_accumulate(m_group, weight, n % half_period == 0), "RMS window");
-        if ((n + 1) % half_period == 0) {
-            must(fdtd3d_group_observe_rms(m_group, m_a.data(), m_a.size()), "RMS download");
-            if (m_out) m_out->write_vti("E_mag_rms", m_a, c.Nx, c.Ny, c.Nz, c.dx, c.dy, c.dz, n + 1);
+        const int next_dump = (n + every - 1) / every * every;                                   // first step >= n that is dumped
+        const int next_done = (n + half_period) / half_period * half_period - 1;                 // first step >= n that completes a window
+        const int last = c.step_by_step ? n : std::min(std::min(next_dump, next_done + 1), c.steps - 1);
+        must(fdtd3d_group_step_observed(m_group, n, last - n + 1, weight, half_period), "step");
+        must(fdtd3d_group_sync(m_group), "sync");
+        m_device_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (next_done <= last) {
+            must(fdtd3d_group_observe_rms_window(m_group, m_a.data(), m_a.size()), "RMS download");
+            if (m_out) m_out->write_vti("E_mag_rms", m_a, c.Nx, c.Ny, c.Nz, c.dx, c.dy, c.dz, next_done + 1);
         }
-        if (n % c.frame_every == 0) {
-            dump_frame(n);
-            std::cout << "[n=" << n << "] frame dumped.\n";
+        if (last % every == 0) {
+            dump_frame(last);
+            std::cout << "[n=" << last << "] frame dumped.\n";
         }
+        n = last + 1;
         m_step_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     std::cout << "Done. VTI in ./" << c.out_dir << "\n";

@@ -11,6 +11,8 @@ int main() {
         sim.run();
         const auto& c = sim.config();
         std::cout << "[timing] " << c.steps << " steps incl. observables and file output: " << sim.seconds_in_steps() << " s\n";
+        std::cout << "[timing] stepping and RMS window on the device: " << sim.seconds_on_device() << " s = "
+                  << sim.seconds_on_device() / (c.steps > 0 ? c.steps : 1) * 1e3 << " ms/step\n";
     } catch (const std::exception& e) {
         std::cerr << "fdtd3d: " << e.what() << std::endl;
         return 1;

@@ -187,8 +187,9 @@ __global__ void k_reduce_finish(const double* slots, double* results, int n_ids)
 
 // Cell-centre observables (FDTD3D::run / dumpFrame, FDTD3D.cpp:1023-1097): every cell averages the
 // four Ex, Ey, Ez samples on its edges.  MODE 0: acc (+)= (1/16)(sx^2 + sy^2 + sz^2) * weight, the
-// running RMS window; MODE 1: out0 = (1/4) sx (centred Ex), out1 = ax^2 + ay^2 + az^2 (|E|^2).
-// Output order is x fastest, then y, then z -- the order the reference hands to its VTI writer.
+// running RMS window, kept [plane][row][column] like a field array (the two-step kernel advances the same
+// array by itself when asked to); MODE 1: out0 = (1/4) sx (centred Ex), out1 = ax^2 + ay^2 + az^2 (|E|^2),
+// x fastest, then y, then z -- the order the reference hands to its VTI writer.
 template <typename T, bool LEAN, int MODE>
 __global__ void k3_observe(const K3<T> a, T* out0, T* out1, T weight, int reset, int nzl) {
     const size_t cells = (size_t)a.Nx * a.Ny * nzl;
@@ -202,13 +203,23 @@ __global__ void k3_observe(const K3<T> a, T* out0, T* out1, T weight, int reset,
         const T s_z = load_e1<T, LEAN>(a, 2, id) + (wall ? (T)0 : load_e1<T, LEAN>(a, 2, id + 1)) + load_e1<T, LEAN>(a, 2, id + a.px) + (wall ? (T)0 : load_e1<T, LEAN>(a, 2, id + a.px + 1));
         if (MODE == 0) {
             const T e_sq = (T)0.0625 * (sx * sx + sy * sy + s_z * s_z);
-            const T old = reset ? (T)0 : out0[t];
-            out0[t] = old + e_sq * weight;
+            const T old = reset ? (T)0 : out0[id];
+            out0[id] = old + e_sq * weight;
         } else {
             const T ax = (T)0.25 * sx, ay = (T)0.25 * sy, az = (T)0.25 * s_z;
             out0[t] = ax;
             out1[t] = ax * ax + ay * ay + az * az;
         }
+    }
+}
+
+// The window array without its padding: [owned layers][Ny][Nx], x fastest.
+template <typename T>
+__global__ void k3_unpad(const T* __restrict__ padded, T* __restrict__ dense, int Nx, int Ny, int nzl, int px, int ny1) {
+    const size_t cells = (size_t)Nx * Ny * nzl;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < cells; t += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(t % Nx), j = (int)((t / Nx) % Ny), kl = 1 + (int)(t / ((size_t)Nx * Ny));
+        dense[t] = padded[((size_t)kl * ny1 + j) * px + i];
     }
 }
 
@@ -289,6 +300,9 @@ struct fdtd3d_engine {
     virtual double spread_gap() = 0;
     virtual int observe_accumulate(double weight, int reset, hipStream_t s) = 0;
     virtual int observe_rms(double* host, size_t n) = 0;
+    virtual int observe_keep_window() = 0;
+    virtual int observe_rms_window(double* host, size_t n) = 0;
+    virtual int step_observed(int n0, int count, double weight, int window, hipStream_t s) = 0;
     virtual int observe_frame(double* ex_center, double* e_mag, size_t n, hipStream_t s) = 0;
     fdtd3d_desc d;
     KernelTimer timer;
@@ -322,8 +336,10 @@ struct Engine3 : fdtd3d_engine {
     T* xrow_d = nullptr;
     T* mag_d = nullptr;
     double* red_d = nullptr;          // reduction scratch: 1024 partial sums + checksum word
-    T* obs_acc = nullptr;             // RMS window accumulator, [owned layers][Ny][Nx]
-    T* obs_tmp = nullptr;             // two frame buffers of the same shape (allocated on first use)
+    T* obs_acc = nullptr;             // RMS window accumulator, [plane][row][column] like a field array
+    T* obs_snap = nullptr;            // the last completed window (observe_keep_window), same shape
+    bool obs_have_window = false;
+    T* obs_tmp = nullptr;             // two frame buffers [owned layers][Ny][Nx] (allocated on first use)
     std::vector<double> tab_h;        // [3][2][6][kMaxLayers], fp64 master copy
     std::vector<T> wf;
     static constexpr int kRemapAuto = 65536;
@@ -1017,13 +1033,27 @@ struct Engine3 : fdtd3d_engine {
 
     // ---- observables ---------------------------------------------------------------------
     size_t obs_cells() const { return (size_t)d.Nx * d.Ny * nzl; }
-    int observe_accumulate(double weight, int reset, hipStream_t s) override {
+    int obs_reserve(bool snap) {
         int rc;
-        if (!obs_acc && (rc = dalloc((void**)&obs_acc, obs_cells() * sizeof(T)))) return rc;
+        if (!obs_acc && (rc = dalloc((void**)&obs_acc, (fsize + px) * sizeof(T)))) return rc;
+        if (snap && !obs_snap && (rc = dalloc((void**)&obs_snap, (fsize + px) * sizeof(T)))) return rc;
+        return FDTD_OK;
+    }
+    int observe_accumulate(double weight, int reset, hipStream_t s) override {
+        if (int rc = obs_reserve(false)) return rc;
         K3<T> a = args();
         if (full) hipLaunchKernelGGL((k3_observe<T, false, 0>), dim3(4096), dim3(256), 0, s, a, obs_acc, (T*)nullptr, (T)weight, reset, nzl);
         else hipLaunchKernelGGL((k3_observe<T, true, 0>), dim3(4096), dim3(256), 0, s, a, obs_acc, (T*)nullptr, (T)weight, reset, nzl);
         FDTD_HIP(hipGetLastError());
+        return FDTD_OK;
+    }
+    // The window as it stands becomes "the last completed window" (observe_rms_window): the two arrays change roles,
+    // nothing is copied.  What the accumulator holds afterwards is undefined: the next accumulation must open a new
+    // window (reset), which is what follows a completed window anyway.
+    int observe_keep_window() override {
+        if (int rc = obs_reserve(true)) return rc;
+        std::swap(obs_acc, obs_snap);
+        obs_have_window = true;
         return FDTD_OK;
     }
     // scatter an [owned layers][Ny][Nx] device array into the global [Nz][Ny][Nx] host array
@@ -1035,10 +1065,59 @@ struct Engine3 : fdtd3d_engine {
         for (size_t q = 0; q < st.size(); ++q) dst[q] = take_sqrt ? std::sqrt((double)st[q]) : (double)st[q];
         return FDTD_OK;
     }
+    int obs_download_window(const T* padded, double* host) {
+        int rc;
+        if (!obs_tmp && (rc = dalloc((void**)&obs_tmp, 2 * obs_cells() * sizeof(T)))) return rc;
+        FDTD_HIP(hipDeviceSynchronize());
+        hipLaunchKernelGGL(k3_unpad<T>, dim3(4096), dim3(256), 0, 0, padded, obs_tmp, d.Nx, d.Ny, nzl, px, ny1);
+        FDTD_HIP(hipGetLastError());
+        return obs_download(obs_tmp, host, true);
+    }
     int observe_rms(double* host, size_t n) override {
         if (n != (size_t)d.Nx * d.Ny * d.Nz || !host) return fail(FDTD_ERR_ARG, "observe_rms: expected %zu values", (size_t)d.Nx * d.Ny * d.Nz);
         if (!obs_acc) return fail(FDTD_ERR_STATE, "observe_rms: nothing accumulated yet");
-        return obs_download(obs_acc, host, true);
+        return obs_download_window(obs_acc, host);
+    }
+    int observe_rms_window(double* host, size_t n) override {
+        if (n != (size_t)d.Nx * d.Ny * d.Nz || !host) return fail(FDTD_ERR_ARG, "observe_rms_window: expected %zu values", (size_t)d.Nx * d.Ny * d.Nz);
+        if (!obs_have_window) return fail(FDTD_ERR_STATE, "observe_rms_window: no window has been completed yet");
+        return obs_download_window(obs_snap, host);
+    }
+    // `count` steps from n0, each followed by the accumulation of FDTD3D::run (FDTD3D.cpp:1089-1097): a new window opens
+    // at every step n with n % window == 0, and the window that step n completes ((n + 1) % window == 0) is kept for
+    // observe_rms_window.  Where fdtd3d_step would take two steps per launch, the launch advances the window by both
+    // of its steps as well (and, when its first step completes a window, keeps it on the way).
+    int step_observed(int n0, int count, double weight, int window, hipStream_t s) override {
+        if (window < 1) return fail(FDTD_ERR_ARG, "step_observed: the window must have at least one step");
+        if (n0 < 0) return fail(FDTD_ERR_ARG, "step_observed: negative step number");
+        if (int rc = obs_reserve(true)) return rc;
+        const bool probed = !probes.specs.empty();
+        for (int n = n0; n < n0 + count;) {
+            if (n + 2 <= n0 + count && pair_auto()) {
+                if (probed) if (int rc = pair_peek_probes(n, s)) return rc;
+                const bool done1 = (n + 1) % window == 0;              // the first step completes a window: the second opens one
+                pair_acc_w = (T)weight;
+                pair_acc_flags = (n % window == 0 ? 1 : 0) | (done1 ? 2 | 4 : 0);
+                const int rc = step_pair(n, s);
+                pair_acc_flags = -1;
+                if (rc == FDTD_OK) {
+                    if (done1) obs_have_window = true;
+                    if ((n + 2) % window == 0) if (int rc2 = observe_keep_window()) return rc2;
+                    if (int rc2 = probe_record(s)) return rc2;
+                    n += 2;
+                    continue;
+                }
+                if (rc != FDTD_ERR_HIP) return rc;                      // (no device memory for the launch: single steps, as fdtd3d_step)
+                if (probed) probe_unrecord();
+                pair_give_up();
+            }
+            if (int rc = step(n, s)) return rc;
+            if (int rc = observe_accumulate(weight, n % window == 0, s)) return rc;
+            if ((n + 1) % window == 0) if (int rc = observe_keep_window()) return rc;
+            if (int rc = probe_record(s)) return rc;
+            ++n;
+        }
+        return FDTD_OK;
     }
     int observe_frame(double* ex_center, double* e_mag, size_t n, hipStream_t s) override {
         if (n != (size_t)d.Nx * d.Ny * d.Nz || !ex_center || !e_mag) return fail(FDTD_ERR_ARG, "observe_frame: expected %zu values per array", (size_t)d.Nx * d.Ny * d.Nz);
@@ -1065,6 +1144,7 @@ struct Engine3 : fdtd3d_engine {
         for (int ax = 0; ax < 3; ++ax) for (int s = 0; s < 2; ++s) a.np[ax][s] = np[ax][s];
         a.xwn = xwn; a.xwp = xwp; a.xp0 = xp0;
         a.wrap_l = 0; a.wrap_r0 = 0; a.peek = 0;
+        a.acc = nullptr; a.acc_snap = nullptr; a.acc_w = (T)0; a.acc_flags = 0;
         a.kJ = d.k_Jx; a.src_on = 0; a.jx = (T)0;
         a.dt = (T)d.dt; a.dtd[0] = (T)(d.dt / d.dx); a.dtd[1] = (T)(d.dt / d.dy); a.dtd[2] = (T)(d.dt / d.dz); a.mu0 = (T)d.mu0;
         a.nbx = px / (kLanes * V); a.nby = (ny1 + wpb - 1) / wpb; a.wpb = wpb;
@@ -1361,7 +1441,8 @@ struct Engine3 : fdtd3d_engine {
         if (r1 <= r0) return FDTD_OK;
         constexpr int PV = V / 2, TW = kLanes * PV;
         const unsigned nblk = pair_plan(a, r0, r1);
-        const size_t lds = ((size_t)6 + (size_t)3 * 2 * wpbp * 2) * TW * sizeof(T);
+        const bool acc = a.acc != nullptr;         // the RMS window rides along: three planes of E1 and E2 rows in LDS instead of two
+        const size_t lds = ((size_t)6 + (size_t)(acc ? 8 : 6) * wpbp * 2) * TW * sizeof(T);
         const size_t scr_need = pml ? (size_t)nblk * wpbp * 24 * TW : 0;
         // the kernel forms a wave's offset into the scratch memory in 32 bits
         if (!fdtd3d_pair_scratch_fits((long long)nblk, wpbp, (int)sizeof(T) * 8))
@@ -1378,7 +1459,10 @@ struct Engine3 : fdtd3d_engine {
             hipLaunchKernelGGL(kern, dim3(nblk), dim3(kLanes * wpbp), lds, s, a);
         };
         timer.begin(3, s, part);
-        if (pml) { if (d.has_mu) go(k3_pair<T, true, true, PV>); else go(k3_pair<T, false, true, PV>); }
+        if (acc) {
+            if (pml) { if (d.has_mu) go(k3_pair<T, true, true, PV, true>); else go(k3_pair<T, false, true, PV, true>); }
+            else { if (d.has_mu) go(k3_pair<T, true, false, PV, true>); else go(k3_pair<T, false, false, PV, true>); }
+        } else if (pml) { if (d.has_mu) go(k3_pair<T, true, true, PV>); else go(k3_pair<T, false, true, PV>); }
         else { if (d.has_mu) go(k3_pair<T, true, false, PV>); else go(k3_pair<T, false, false, PV>); }
         timer.end(s);
         FDTD_HIP(hipGetLastError());
@@ -1389,6 +1473,8 @@ struct Engine3 : fdtd3d_engine {
     // with fdtd3d_fused), PART_INTERIOR = the rest.
     int pair_phase = 0;
     hipStream_t pair_stream = nullptr;
+    T pair_acc_w = (T)0;              // step_observed: weight and flags of the window the next two-step launch advances
+    int pair_acc_flags = -1;          // (-1: the launch leaves the window alone)
     static constexpr int kPairEdge = 3;
     int step_pair_part(int n, int part, hipStream_t s) override {
         if (!fused) return fail(FDTD_ERR_STATE, "two-step launches need an engine created with FDTD3D_MODE_FUSED");
@@ -1407,6 +1493,11 @@ struct Engine3 : fdtd3d_engine {
         a.src_on = (s1 ? 1 : 0) | (s2 ? 2 : 0);
         a.jx = s1 ? a.dt * wf[n] : (T)0;
         a.jx2 = s2 ? a.dt * wf[n + 1] : (T)0;
+        a.acc = nullptr; a.acc_snap = nullptr; a.acc_w = (T)0; a.acc_flags = 0;
+        if (pair_acc_flags >= 0) {
+            if (part != FDTD3D_PART_ALL) return fail(FDTD_ERR_STATE, "two-step launches advance the RMS window only as a whole launch");
+            a.acc = obs_acc; a.acc_snap = obs_snap; a.acc_w = pair_acc_w; a.acc_flags = pair_acc_flags;
+        }
         if (pml && !phM2_ready) {
             for (int c = 0; c < 3; ++c) for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd)
                 if (phM[c][ax][sd])
@@ -1633,6 +1724,14 @@ int fdtd3d_launch_shape(fdtd3d_handle h, int out[6]) {
 int fdtd3d_tune(fdtd3d_handle h, int chunk, int remap, int rows) { return entry(h, [&] { return h->tune(chunk, remap, rows); }); }
 int fdtd3d_observe_accumulate(fdtd3d_handle h, double weight, int reset, void* stream) { return entry(h, [&] { return h->observe_accumulate(weight, reset, (hipStream_t)stream); }); }
 int fdtd3d_observe_rms(fdtd3d_handle h, double* host, size_t n) { return entry(h, [&] { return h->observe_rms(host, n); }); }
+int fdtd3d_observe_keep_window(fdtd3d_handle h) { return entry(h, [&] { return h->observe_keep_window(); }); }
+int fdtd3d_observe_rms_window(fdtd3d_handle h, double* host, size_t n) { return entry(h, [&] { return h->observe_rms_window(host, n); }); }
+int fdtd3d_step_observed(fdtd3d_handle h, int n0, int count, double weight, int window, void* stream) {
+    return entry(h, [&]() -> int {
+        if (h->d.z_lo != 0 || h->d.z_hi != h->d.Nz) return fail(FDTD_ERR_STATE, "fdtd3d_step_observed needs the whole grid on this device; slab drivers step and call fdtd3d_observe_accumulate themselves");
+        return h->step_observed(n0, count, weight, window, (hipStream_t)stream);
+    });
+}
 int fdtd3d_observe_frame(fdtd3d_handle h, double* ex_center, double* e_mag, size_t n, void* stream) { return entry(h, [&] { return h->observe_frame(ex_center, e_mag, n, (hipStream_t)stream); }); }
 int fdtd3d_kernel_timing(fdtd3d_handle h, int enable) {
     if (!h) return fail(FDTD_ERR_ARG, "null handle");

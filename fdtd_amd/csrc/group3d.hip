@@ -322,6 +322,28 @@ int fdtd3d_group_observe_accumulate(fdtd3d_group_handle g, double weight, int re
 int fdtd3d_group_observe_rms(fdtd3d_group_handle g, double* host, size_t n) {
     return each_member(g, [&](fdtd3d_handle h) { return fdtd3d_observe_rms(h, host, n); });
 }
+int fdtd3d_group_observe_rms_window(fdtd3d_group_handle g, double* host, size_t n) {
+    return each_member(g, [&](fdtd3d_handle h) { return fdtd3d_observe_rms_window(h, host, n); });
+}
+// Steps with the RMS window of FDTD3D::run (FDTD3D.cpp:1089-1103) advanced after every one of them.  One slab: the
+// engine's own fdtd3d_step_observed (two steps per launch where that pays).  Several: step, accumulate on every slab,
+// and where a step completes a window every slab keeps it.
+int fdtd3d_group_step_observed(fdtd3d_group_handle g, int n0, int count, double weight, int window) {
+    if (!g) return fail(FDTD_ERR_ARG, "null group");
+    if (window < 1 || n0 < 0) return fail(FDTD_ERR_ARG, "group_step_observed: bad window or step number");
+    if (g->member.size() == 1) {
+        DeviceScope scope(g->device[0]);
+        return fdtd3d_step_observed(g->member[0], n0, count, weight, window, g->run[0]);
+    }
+    for (int n = n0; n < n0 + count; ++n) {
+        if (int rc = g->fused ? step_fused(g, n) : step_halves(g, n)) return rc;
+        for (size_t r = 0; r < g->member.size(); ++r) {
+            if (int rc = fdtd3d_observe_accumulate(g->member[r], weight, n % window == 0, g->run[r])) return rc;
+            if ((n + 1) % window == 0) if (int rc = fdtd3d_observe_keep_window(g->member[r])) return rc;
+        }
+    }
+    return FDTD_OK;
+}
 int fdtd3d_group_observe_frame(fdtd3d_group_handle g, double* ex_center, double* e_mag, size_t n) {
     if (!g) return fail(FDTD_ERR_ARG, "null group");
     for (size_t r = 0; r < g->member.size(); ++r)

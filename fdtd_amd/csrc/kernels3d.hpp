@@ -63,6 +63,13 @@ struct K3 {
     // columns from wrap_r0 on), so that one x tile instead of two meets the x-face CPML strips; 0 = tiles in a row
     int wrap_l, wrap_r0;
     int peek;          // one-step fused kernel: leave the B-side CPML state (updated in place) as it is -- a launch whose results are only sampled
+    // two-step kernel with the RMS window folded in: the window [plane][row][column] like a field array, the array that
+    // keeps a window as the launch's FIRST step leaves it, the weight, and flags (1: the first step opens a new window,
+    // 2: the second step does, 4: keep the window after the first step)
+    T* acc;
+    T* acc_snap;
+    T acc_w;
+    int acc_flags;
 };
 
 template <typename T, int V>

@@ -98,7 +98,11 @@ __device__ __forceinline__ void pair_cpml_x(Pack<T, V>& d, const Pack<T, V>& cur
     }
 }
 
-template <typename T, bool MU, bool PML, int V>
+// ACC: the launch also advances the running RMS window of the cell-centred |E|^2 (FDTD3D::run, FDTD3D.cpp:1074-1097)
+// by both of its steps: acc(cell) (+)= (1/16)((sum4 Ex)^2 + (sum4 Ey)^2 + (sum4 Ez)^2) * weight after each step, in the
+// reference's order of additions, from E1 and E2 while they are on chip.  The rows of the last THREE planes then stay in
+// LDS (instead of two), so that a wave finds the row above of two consecutive planes there after the barrier.
+template <typename T, bool MU, bool PML, int V, bool ACC = false>
 __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_eu(4, 4))) k3_pair(const K3<T> a) {
     static_assert(V <= 2, "the two halo columns on either side must be whole packs");
     constexpr int TW = kLanes * V;                       // columns a wave computes
@@ -178,10 +182,12 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
 
         // LDS: [6][TW] x coefficients (b, a, C of the D side, then of the B side); then three regions
         // [2 planes][W rows][2 comps][TW]: E1 (x, z) for the row below, H1 (x, z) for the row above, E2 (x, z) for the row below
+        // (ACC: three planes of E1 and of E2)
+        constexpr int NB = ACC ? 3 : 2;
         T* const xs = smem;
-        const size_t region = (size_t)2 * W * 2 * TW;
+        const size_t region = (size_t)2 * W * 2 * TW, region_e = (size_t)NB * W * 2 * TW;
         T* const e1s = smem + 6 * TW;
-        T* const h1s = e1s + region;
+        T* const h1s = e1s + region_e;
         T* const e2s = h1s + region;
         for (int q = w; q < 6; q += W) lds_st<T, V>(xs + (size_t)q * TW + lo, ldg<T, V>(a.xrow + (size_t)q * px + c0, lc));
         __syncthreads();
@@ -358,8 +364,33 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             b0_km[c] = mu_km[c] = e1_km[c] = d1_km[c] = ep_km[c] = b1_km2[c] = e2_km2[c] = zero_pack<T, V>();
         }
         h1_km2[0] = h1_km2[1] = zero_pack<T, V>();
+        // ACC: the window value of the cells one and two planes back after their first step, and Ey2(i) + Ey2(i+1) of the
+        // plane whose own row has left the registers (the rest of that plane is read back from LDS)
+        P acc_km1 = zero_pack<T, V>(), acc_km2 = zero_pack<T, V>(), ey2_pair = zero_pack<T, V>();
+        int q3 = ACC ? (kb - 1) % 3 : 0;                             // ACC: which of the three LDS planes this iteration writes
+        // a pack shifted one column to the left: element e becomes the value of column e + 1
+        auto shl = [&](const P& x) -> P {
+            P r;
+#pragma unroll
+            for (int e = 0; e + 1 < V; ++e) r.v[e] = x.v[e + 1];
+            r.v[V - 1] = right_of_tile(__shfl_down(x.v[0], 1));
+            return r;
+        };
+        // (1/16)((sum of four)^2 + ...), each sum left to right as FDTD3D.cpp:1075-1081
+        auto center_sq = [&](const P& x0, const P& x1, const P& x2, const P& x3, const P& y01, const P& y2, const P& y3,
+                             const P& z0, const P& z1, const P& z2, const P& z3) -> P {
+            P r;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const T sx = ((x0.v[e] + x1.v[e]) + x2.v[e]) + x3.v[e];
+                const T sy = (y01.v[e] + y2.v[e]) + y3.v[e];
+                const T s_z = ((z0.v[e] + z1.v[e]) + z2.v[e]) + z3.v[e];
+                r.v[e] = (T)0.0625 * ((sx * sx + sy * sy) + s_z * s_z);
+            }
+            return r;
+        };
 
-        for (int kl = kb - 1; kl <= ke + 1; ++kl) {
+        for (int kl = kb - 1; kl <= ke + (ACC ? 2 : 1); ++kl) {
             asm volatile("" : "+s"(ap));
             // Issue priority by stage: a wave that is about to request its planes goes first on its SIMD, so that its loads
             // travel while the other waves do arithmetic; the stage in front of the next iteration's loads comes second
@@ -369,6 +400,8 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             const size_t ro = ((size_t)klc * a.ny1 + j) * px + c0;
             const int k = kl + a.zoff;
             const int par = kl & 1;
+            // LDS planes of the E rows: written by this iteration, by the one before, by the one before that
+            const int ecur = ACC ? q3 : par, eprev = ACC ? (q3 == 0 ? 2 : q3 - 1) : (par ^ 1), eprev2 = ACC ? (q3 == 2 ? 0 : q3 + 1) : 0;
 
             // ------------------------------------------------------------ A: D1(k), E1(k)
             P bo[3], mu_[3], d1[3], ep[3];
@@ -405,7 +438,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             P e1[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) e1[c] = divide<T, V>(d1[c], ep[c]);
-            lds_st<T, V>(slot(e1s, par, w), e1[0]); lds_st<T, V>(slot(e1s, par, w) + TW, e1[2]);
+            lds_st<T, V>(slot(e1s, ecur, w), e1[0]); lds_st<T, V>(slot(e1s, ecur, w) + TW, e1[2]);
 
             // ------------------------------------------------------------ B: B1(k-1), H1(k-1)
             __builtin_amdgcn_s_setprio(0);
@@ -413,7 +446,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
 #pragma unroll
             for (int c = 0; c < 3; ++c) { b1[c] = b0_km[c]; h1[c] = zero_pack<T, V>(); }
             if (kl >= kb) {
-                const T* up = slot(e1s, par ^ 1, w_up);              // E1(k-1) of the row above, published one iteration ago
+                const T* up = slot(e1s, eprev, w_up);                // E1(k-1) of the row above, published one iteration ago
                 const P ex_jp = lds_ld<T, V>(up), ez_jp = lds_ld<T, V>(up + TW);
                 const T ey_r = right_of_tile(__shfl_down(e1_km[1].v[0], 1)), ez_r = right_of_tile(__shfl_down(e1_km[2].v[0], 1));
                 update_b(b1, e1_km, e1, ex_jp, ez_jp, ey_r, ez_r, kl - 1, k - 1, 0, par ^ 1, false, famB, preB0, preB1);
@@ -452,25 +485,79 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
                 }
 #pragma unroll
                 for (int c = 0; c < 3; ++c) e2[c] = divide<T, V>(d2[c], ep_km[c]);
-                lds_st<T, V>(slot(e2s, par, w), e2[0]); lds_st<T, V>(slot(e2s, par, w) + TW, e2[2]);
+                lds_st<T, V>(slot(e2s, ecur, w), e2[0]); lds_st<T, V>(slot(e2s, ecur, w) + TW, e2[2]);
             }
 
             // ------------------------------------------------------------ D: B2(k-2)
             __builtin_amdgcn_s_setprio(1);
             if (kl >= kb + 2) {
-                const T* up = slot(e2s, par ^ 1, w_up);              // E2(k-2) of the row above, published one iteration ago
+                const T* up = slot(e2s, eprev, w_up);                // E2(k-2) of the row above, published one iteration ago
                 const P ex_jp = lds_ld<T, V>(up), ez_jp = lds_ld<T, V>(up + TW);
                 const T ey_r = right_of_tile(__shfl_down(e2_km2[1].v[0], 1)), ez_r = right_of_tile(__shfl_down(e2_km2[2].v[0], 1));
                 const int km2 = k - 2;
                 const bool bl_lt = km2 >= 0 && km2 < Nz;
                 P b2[3] = {b1_km2[0], b1_km2[1], b1_km2[2]};
-                update_b(b2, e2_km2, e2, ex_jp, ez_jp, ey_r, ez_r, kl - 2, km2, 1, par, own, famD, preD0, preD1);
-                if (own) {
+                const bool st = own && (!ACC || kl - 2 < ke);        // (ACC: the loop runs one iteration longer)
+                update_b(b2, e2_km2, e2, ex_jp, ez_jp, ey_r, ez_r, kl - 2, km2, 1, par, st, famD, preD0, preD1);
+                if (st) {
                     const size_t rs = ro - sz * (size_t)(klc - (kl - 2));
                     if (row_lt && bl_lt) stg_nt<T, V>(ap->Bn[0] + rs, lc, b2[0]);
                     if (bl_lt) stg_nt<T, V>(ap->Bn[1] + rs, lc, b2[1]);
                     if (row_lt) stg_nt<T, V>(ap->Bn[2] + rs, lc, b2[2]);
                 }
+            }
+
+            // ------------------------------------------------------------ ACC: the RMS window of both steps
+            if constexpr (ACC) {
+                asm volatile("" : "+s"(ap));
+                const T wgt = ap->acc_w;
+                const int flags = ap->acc_flags;          // 1: the first step opens a new window, 2: the second does, 4: keep the window as the first step leaves it
+                // first step, cells between the planes k-1 and k: own rows in registers, the row above in LDS (plane k
+                // published before this iteration's barrier, plane k-1 one iteration earlier)
+                P a1 = zero_pack<T, V>();
+                if (kl >= kb + 1) {
+                    const T* u1 = slot(e1s, ecur, w_up);
+                    const T* u0 = slot(e1s, eprev, w_up);
+                    const P xu1 = lds_ld<T, V>(u1), xu0 = lds_ld<T, V>(u0), zu0 = lds_ld<T, V>(u0 + TW);
+                    P y01;
+                    {
+                        const P r = shl(e1_km[1]);
+#pragma unroll
+                        for (int e = 0; e < V; ++e) y01.v[e] = e1_km[1].v[e] + r.v[e];
+                    }
+                    const P c = center_sq(e1_km[0], xu0, e1[0], xu1, y01, e1[1], shl(e1[1]), e1_km[2], shl(e1_km[2]), zu0, shl(zu0));
+                    const int km = k - 1;
+                    const bool on = own && kl - 1 < ke && row_lt && km >= 0 && km < Nz;
+                    const size_t rs = ro - sz * (size_t)(klc - (kl - 1));
+                    if (on && !(flags & 1)) a1 = ldg<T, V>(ap->acc + rs, lc);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) a1.v[e] = a1.v[e] + c.v[e] * wgt;
+                    if (on && (flags & 4)) stg<T, V>(ap->acc_snap + rs, lc, a1);
+                }
+                // second step, cells between the planes k-3 and k-2: E2(k-2) of the own row in registers, of the row above
+                // in LDS; E2(k-3) in LDS (x, z) and in `ey2_pair` (y)
+                if (kl >= kb + 3) {
+                    const T* o3 = slot(e2s, eprev2, w);
+                    const T* u3 = slot(e2s, eprev2, w_up);
+                    const T* u2 = slot(e2s, eprev, w_up);
+                    const P xo3 = lds_ld<T, V>(o3), zo3 = lds_ld<T, V>(o3 + TW), xu3 = lds_ld<T, V>(u3), zu3 = lds_ld<T, V>(u3 + TW), xu2 = lds_ld<T, V>(u2);
+                    const P c = center_sq(xo3, xu3, e2_km2[0], xu2, ey2_pair, e2_km2[1], shl(e2_km2[1]), zo3, shl(zo3), zu3, shl(zu3));
+                    const int km3 = k - 3;
+                    const bool on = own && kl - 3 < ke && row_lt && km3 >= 0 && km3 < Nz;
+                    const size_t rs = ((size_t)(kl - 3) * a.ny1 + j) * px + c0;
+                    P out = acc_km2;
+                    if (flags & 2) out = zero_pack<T, V>();
+#pragma unroll
+                    for (int e = 0; e < V; ++e) out.v[e] = out.v[e] + c.v[e] * wgt;
+                    if (on) stg<T, V>(ap->acc + rs, lc, out);
+                }
+                {
+                    const P r = shl(e2_km2[1]);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) ey2_pair.v[e] = e2_km2[1].v[e] + r.v[e];
+                }
+                acc_km2 = acc_km1; acc_km1 = a1;
+                q3 = q3 == 2 ? 0 : q3 + 1;
             }
 
             // ------------------------------------------------------------ hand-over to the next iteration

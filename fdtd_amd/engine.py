@@ -312,6 +312,21 @@ class Engine3D(_Common):
         _check(lib().fdtd3d_observe_rms(self.h, out.ctypes.data_as(_dp), C.c_size_t(n)), "fdtd3d_observe_rms")
         return out
 
+    def step_observed(self, n0: int, count: int, weight: float, window: int, stream=None) -> None:
+        """`count` steps, the RMS window advanced after each (fdtd3d_step_observed)."""
+        _check(lib().fdtd3d_step_observed(self.h, C.c_int(n0), C.c_int(count), C.c_double(weight), C.c_int(window), _stream_handle(stream)),
+               "fdtd3d_step_observed")
+
+    def observe_keep_window(self) -> None:
+        _check(lib().fdtd3d_observe_keep_window(self.h), "fdtd3d_observe_keep_window")
+
+    def observe_rms_window(self, out=None) -> np.ndarray:
+        """sqrt of the last completed window."""
+        n = self.N[0] * self.N[1] * self.N[2]
+        out = np.zeros(n) if out is None else out
+        _check(lib().fdtd3d_observe_rms_window(self.h, out.ctypes.data_as(_dp), C.c_size_t(n)), "fdtd3d_observe_rms_window")
+        return out
+
     def observe_frame(self, stream=None):
         n = self.N[0] * self.N[1] * self.N[2]
         a, b = np.zeros(n), np.zeros(n)
@@ -395,6 +410,14 @@ class EngineGroup3D:
     def observe_rms(self) -> np.ndarray:
         out = np.zeros(self.N[0] * self.N[1] * self.N[2])
         _check(lib().fdtd3d_group_observe_rms(self.h, out.ctypes.data_as(_dp), C.c_size_t(out.size)), "fdtd3d_group_observe_rms")
+        return out
+
+    def step_observed(self, n0: int, count: int, weight: float, window: int) -> None:
+        _check(lib().fdtd3d_group_step_observed(self.h, C.c_int(n0), C.c_int(count), C.c_double(weight), C.c_int(window)), "fdtd3d_group_step_observed")
+
+    def observe_rms_window(self) -> np.ndarray:
+        out = np.zeros(self.N[0] * self.N[1] * self.N[2])
+        _check(lib().fdtd3d_group_observe_rms_window(self.h, out.ctypes.data_as(_dp), C.c_size_t(out.size)), "fdtd3d_group_observe_rms_window")
         return out
 
     def observe_frame(self):

@@ -253,6 +253,20 @@ int fdtd3d_reduce_static(fdtd3d_handle h, const int* ids, int n_ids, double* sum
  *   frame:      ex_center = (1/4) sum4 Ex, e_mag = sqrt(ax^2+ay^2+az^2) (FDTD3D.cpp:1035-1051) */
 int fdtd3d_observe_accumulate(fdtd3d_handle h, double weight, int reset, void* stream);
 int fdtd3d_observe_rms(fdtd3d_handle h, double* host, size_t n);
+/* The loop body of FDTD3D::run() (FDTD3D.cpp:1085-1097) for `count` steps from n0: step, then accumulate with
+ * `weight`; a new window opens (the accumulator is zeroed first) at every step n with n % window == 0, and the
+ * window that a step n completes ((n + 1) % window == 0; the reference writes it out there, FDTD3D.cpp:1098-1103)
+ * is kept and can be fetched with fdtd3d_observe_rms_window() until the next one completes.  Where fdtd3d_step
+ * would take two steps per launch, the launch advances the window by both of its steps from the E values it has
+ * on chip -- same additions in the same order, so the window equals, bit for bit, what step + accumulate per step
+ * give; a window completed by the first step of such a launch is kept on the way.  Whole-grid engines only.
+ *   keep_window: what fdtd3d_step_observed does when a step completes a window, for callers that step and
+ *                accumulate themselves (slab drivers): the accumulator as it stands becomes the kept window
+ *                (no copy: the two arrays change roles), and the next accumulate must open a new window.
+ *   rms_window:  host = sqrt(kept window), laid out like fdtd3d_observe_rms. */
+int fdtd3d_step_observed(fdtd3d_handle h, int n0, int count, double weight, int window, void* stream);
+int fdtd3d_observe_keep_window(fdtd3d_handle h);
+int fdtd3d_observe_rms_window(fdtd3d_handle h, double* host, size_t n);
 int fdtd3d_observe_frame(fdtd3d_handle h, double* ex_center, double* e_mag, size_t n, void* stream);
 
 /* Probe time series (no counterpart in the reference, which has no probes; the value sampled is the
@@ -346,6 +360,8 @@ int fdtd3d_group_fill_materials(fdtd3d_group_handle g, uint64_t seed, double eps
 int fdtd3d_group_fill_reference_materials(fdtd3d_group_handle g);
 int fdtd3d_group_observe_accumulate(fdtd3d_group_handle g, double weight, int reset);
 int fdtd3d_group_observe_rms(fdtd3d_group_handle g, double* host, size_t n);
+int fdtd3d_group_step_observed(fdtd3d_group_handle g, int n0, int count, double weight, int window);
+int fdtd3d_group_observe_rms_window(fdtd3d_group_handle g, double* host, size_t n);
 int fdtd3d_group_observe_frame(fdtd3d_group_handle g, double* ex_center, double* e_mag, size_t n);
 
 /* ------------------------------------------------------------------ 2-D -- */

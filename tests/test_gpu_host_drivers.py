@@ -48,6 +48,26 @@ def test_fdtd3d_driver_writes_the_reference_files(tmp_path):
     assert "E_mag_rms_t00040.vti" in names and "Ex_t00020.vti" in names
 
 
+def test_fdtd3d_driver_with_the_window_inside_two_step_launches(tmp_path):
+    """FDTD_PAIR=1 makes the engine take two steps per launch on this small grid too: the driver's runs of steps then go
+    through the two-step kernel with the RMS window advanced inside it, completed windows kept on the way (the window
+    of 20 steps completes on the first step of a launch) -- and the files are still the reference's, byte for byte."""
+    fx = os.path.join(util.GOLDEN, "run3d")
+    meta = json.load(open(os.path.join(fx, "meta.json")))
+    env = dict(FDTD3D_NX=meta["N"][0], FDTD3D_NY=meta["N"][1], FDTD3D_NZ=meta["N"][2], FDTD3D_NPML=meta["npml"][0],
+               FDTD3D_STEPS=meta["steps"], FDTD3D_PRECISION=64, FDTD_PAIR=1)
+    out = _run("fdtd3d", env, str(tmp_path))
+    assert "[n=40] frame dumped." in out
+    _compare_dir(str(tmp_path / "output_3d"), fx)
+    _run("fdtd3d", dict(env, FDTD3D_FRAME_EVERY=7), str(tmp_path))          # dumps at steps that are first steps of a launch as well
+    names = sorted(os.listdir(str(tmp_path / "output_3d")))
+    for n in names:
+        if n.startswith("E_mag_rms"):
+            want = gzip.open(os.path.join(fx, n + ".gz"), "rb").read()
+            assert open(str(tmp_path / "output_3d" / n), "rb").read() == want, n
+    assert "Ex_t00007.vti" in names and "Ex_t00035.vti" in names
+
+
 def test_fdtd3d_driver_full_storage_and_fp32(tmp_path):
     fx = os.path.join(util.GOLDEN, "run3d")
     meta = json.load(open(os.path.join(fx, "meta.json")))
