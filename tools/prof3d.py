@@ -23,6 +23,7 @@ ap.add_argument("--rows", type=int, default=0)
 ap.add_argument("--precision", type=int, default=32)
 ap.add_argument("--no-mu", action="store_true")
 ap.add_argument("--npml", type=int, default=20)
+ap.add_argument("--noise", action="store_true", help="every cell of D and B non-zero before the steps (counter-hash noise)")
 args = ap.parse_args()
 
 n = args.n
@@ -43,6 +44,10 @@ if os.environ.get("FDTD_SHAPE_OUT"):            # for tools/pmc_traffic.py: the 
     import json
     with open(os.environ["FDTD_SHAPE_OUT"], "w") as f:
         json.dump(eng.stamp_shape(), f)
+if args.noise:
+    for c in range(3):
+        eng.fill_array(fdtd_amd.engine.DX + c, 7, -1e-11, 1e-11)
+        eng.fill_array(fdtd_amd.engine.BX + c, 7, -1e-8, 1e-8)
 eng.step(0, args.steps)
 torch.cuda.synchronize()
 print("done", args.mode, n, args.steps)
