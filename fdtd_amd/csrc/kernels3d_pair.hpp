@@ -194,6 +194,10 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
         const P xcd = lds_ld<T, V>(xs + 2 * TW + lo), xch = lds_ld<T, V>(xs + 5 * TW + lo);
         auto slot = [&](T* reg, int par, int row) -> T* { return reg + ((size_t)(par * W + row) * 2) * TW + lo; };
         const int w_up = w + 1 < W ? w + 1 : w, w_dn = w >= 1 ? w - 1 : w;
+        // What a halo row has to deliver decides which stages its wave runs: the row below the owned ones only H1 (stages
+        // A, B), the first row above them E1, H1 and E2 (A, B, C), the second one only E1 (A).  Six of a workgroup's 64
+        // stage executions per iteration are saved that way; the waves still meet at the barrier.
+        const bool do_b = w <= W - 2, do_c = w >= 1 && w <= W - 2, do_d = w >= 1 && w <= W - 3;
         // CPML state between the two steps of a cell: 12 terms x 2 planes in flight, private to the wave, in device memory
         // (only touched inside the layers; the second step reads it back one iteration later, from L2)
         // (what only the layers need -- array extents, table and scratch pointers -- is read from the argument block
@@ -423,7 +427,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             // the CPML state this iteration's first-step terms start from (one family of layers per stage, see `family`)
             int lkA, lkB;
             const int zkA = zone_e(k, Nz, a.np[2][0], a.np[2][1], lkA), zkB = zone_h(k - 1, Nz, a.np[2][0], a.np[2][1], true, lkB);
-            const int famA = LAYERS ? family(y_layer_e, zkA) : 0, famB = (LAYERS && kl >= kb) ? family(y_layer_h, zkB) : 0;
+            const int famA = LAYERS ? family(y_layer_e, zkA) : 0, famB = (LAYERS && do_b && kl >= kb) ? family(y_layer_h, zkB) : 0;
             const int klm = kl >= 1 ? (kl - 1 < a.nzp ? kl - 1 : a.nzp - 1) : 0;
             const P preA0 = request(famA, false, 0, 0, klc, zkA, lkA, par), preA1 = request(famA, false, 1, 0, klc, zkA, lkA, par);
             const P preB0 = request(famB, true, 0, 0, klm, zkB, lkB, par ^ 1), preB1 = request(famB, true, 1, 0, klm, zkB, lkB, par ^ 1);
@@ -445,7 +449,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             P b1[3], h1[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) { b1[c] = b0_km[c]; h1[c] = zero_pack<T, V>(); }
-            if (kl >= kb) {
+            if (do_b && kl >= kb) {
                 const T* up = slot(e1s, eprev, w_up);                // E1(k-1) of the row above, published one iteration ago
                 const P ex_jp = lds_ld<T, V>(up), ez_jp = lds_ld<T, V>(up + TW);
                 const T ey_r = right_of_tile(__shfl_down(e1_km[1].v[0], 1)), ez_r = right_of_tile(__shfl_down(e1_km[2].v[0], 1));
@@ -458,7 +462,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             // before the barrier, so that the wait for the other waves covers its way from L2
             int lkC, lkD;
             const int zkC = zone_e(k - 1, Nz, a.np[2][0], a.np[2][1], lkC), zkD = zone_h(k - 2, Nz, a.np[2][0], a.np[2][1], true, lkD);
-            const int famC = (LAYERS && kl >= kb + 1) ? family(y_layer_e, zkC) : 0, famD = (LAYERS && kl >= kb + 2) ? family(y_layer_h, zkD) : 0;
+            const int famC = (LAYERS && do_c && kl >= kb + 1) ? family(y_layer_e, zkC) : 0, famD = (LAYERS && do_d && kl >= kb + 2) ? family(y_layer_h, zkD) : 0;
             const P preC0 = request(famC, false, 0, 1, 0, zkC, lkC, par ^ 1), preC1 = request(famC, false, 1, 1, 0, zkC, lkC, par ^ 1);
             const P preD0 = request(famD, true, 0, 1, 0, zkD, lkD, par), preD1 = request(famD, true, 1, 1, 0, zkD, lkD, par);
             __syncthreads();
@@ -467,7 +471,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             P e2[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) e2[c] = zero_pack<T, V>();
-            if (kl >= kb + 1) {
+            if (do_c && kl >= kb + 1) {
                 asm volatile("" : "+s"(ap));
                 const T* dn = slot(h1s, par, w_dn);                  // H1(k-1) of the row below, published before the barrier
                 P hx_jm1 = lds_ld<T, V>(dn), hz_jm1 = lds_ld<T, V>(dn + TW);
@@ -490,7 +494,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
 
             // ------------------------------------------------------------ D: B2(k-2)
             __builtin_amdgcn_s_setprio(1);
-            if (kl >= kb + 2) {
+            if (do_d && kl >= kb + 2) {
                 const T* up = slot(e2s, eprev, w_up);                // E2(k-2) of the row above, published one iteration ago
                 const P ex_jp = lds_ld<T, V>(up), ez_jp = lds_ld<T, V>(up + TW);
                 const T ey_r = right_of_tile(__shfl_down(e2_km2[1].v[0], 1)), ez_r = right_of_tile(__shfl_down(e2_km2[2].v[0], 1));
@@ -515,7 +519,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
                 // first step, cells between the planes k-1 and k: own rows in registers, the row above in LDS (plane k
                 // published before this iteration's barrier, plane k-1 one iteration earlier)
                 P a1 = zero_pack<T, V>();
-                if (kl >= kb + 1) {
+                if (do_d && kl >= kb + 1) {
                     const T* u1 = slot(e1s, ecur, w_up);
                     const T* u0 = slot(e1s, eprev, w_up);
                     const P xu1 = lds_ld<T, V>(u1), xu0 = lds_ld<T, V>(u0), zu0 = lds_ld<T, V>(u0 + TW);
@@ -536,7 +540,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
                 }
                 // second step, cells between the planes k-3 and k-2: E2(k-2) of the own row in registers, of the row above
                 // in LDS; E2(k-3) in LDS (x, z) and in `ey2_pair` (y)
-                if (kl >= kb + 3) {
+                if (do_d && kl >= kb + 3) {
                     const T* o3 = slot(e2s, eprev2, w);
                     const T* u3 = slot(e2s, eprev2, w_up);
                     const T* u2 = slot(e2s, eprev, w_up);
