@@ -50,6 +50,26 @@ __device__ __forceinline__ void lds_st(T* p, const Pack<T, V>& r) {
 }
 template <typename T> __device__ __forceinline__ Pack<T, 1> lds_ld1(const T* p) { Pack<T, 1> r; r.v[0] = *p; return r; }
 
+// The value the neighbouring lane holds: lane i receives lane i-1's (`lane_below`) or lane i+1's (`lane_above`); the
+// first (last) lane keeps its own.  One data-parallel-primitive move across the whole wave (wave_shr:1 / wave_shl:1)
+// instead of a permute through the LDS unit, which the row exchanges of the kernel keep busy enough.
+template <int CTRL>
+__device__ __forceinline__ int wave_shift_bits(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false); }
+template <int CTRL, typename T>
+__device__ __forceinline__ T wave_shift(T x) {
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(T, wave_shift_bits<CTRL>(__builtin_bit_cast(int, x)));
+    } else {
+        static_assert(sizeof(T) == 8, "32- or 64-bit values");
+        struct Two { int lo, hi; } t = __builtin_bit_cast(Two, x);
+        t.lo = wave_shift_bits<CTRL>(t.lo);
+        t.hi = wave_shift_bits<CTRL>(t.hi);
+        return __builtin_bit_cast(T, t);
+    }
+}
+template <typename T> __device__ __forceinline__ T lane_below(T x) { return wave_shift<0x138>(x); }
+template <typename T> __device__ __forceinline__ T lane_above(T x) { return wave_shift<0x130>(x); }
+
 // d +- c * curl with a wave-uniform coefficient (the plain update between CPML layers); `skip0` leaves
 // the first element alone (tangential component on the wall column i = 0)
 template <int SIGN, typename T, int V>
@@ -377,7 +397,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             P r;
 #pragma unroll
             for (int e = 0; e + 1 < V; ++e) r.v[e] = x.v[e + 1];
-            r.v[V - 1] = right_of_tile(__shfl_down(x.v[0], 1));
+            r.v[V - 1] = right_of_tile(lane_above(x.v[0]));
             return r;
         };
         // (1/16)((sum of four)^2 + ...), each sum left to right as FDTD3D.cpp:1075-1081
@@ -436,7 +456,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             P hx_jm = zero_pack<T, V>(), hz_jm = zero_pack<T, V>();
             if (j >= 1) { hx_jm = h_of(b0j, m0j); hz_jm = h_of(b2j, m2j); }
             {
-                const T hy_l = left_of_tile(__shfl_up(hy.v[V - 1], 1)), hz_l = left_of_tile(__shfl_up(hz.v[V - 1], 1));
+                const T hy_l = left_of_tile(lane_below(hy.v[V - 1])), hz_l = left_of_tile(lane_below(hz.v[V - 1]));
                 update_d(d1, hx, hy, hz, hx_km, hy_km, hx_jm, hz_jm, hy_l, hz_l, kl, k, 0, par, false, famA, preA0, preA1);
             }
             P e1[3];
@@ -452,7 +472,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             if (do_b && kl >= kb) {
                 const T* up = slot(e1s, eprev, w_up);                // E1(k-1) of the row above, published one iteration ago
                 const P ex_jp = lds_ld<T, V>(up), ez_jp = lds_ld<T, V>(up + TW);
-                const T ey_r = right_of_tile(__shfl_down(e1_km[1].v[0], 1)), ez_r = right_of_tile(__shfl_down(e1_km[2].v[0], 1));
+                const T ey_r = right_of_tile(lane_above(e1_km[1].v[0])), ez_r = right_of_tile(lane_above(e1_km[2].v[0]));
                 update_b(b1, e1_km, e1, ex_jp, ez_jp, ey_r, ez_r, kl - 1, k - 1, 0, par ^ 1, false, famB, preB0, preB1);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) h1[c] = h_of(b1[c], mu_km[c]);
@@ -476,7 +496,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
                 const T* dn = slot(h1s, par, w_dn);                  // H1(k-1) of the row below, published before the barrier
                 P hx_jm1 = lds_ld<T, V>(dn), hz_jm1 = lds_ld<T, V>(dn + TW);
                 if (j < 1) { hx_jm1 = zero_pack<T, V>(); hz_jm1 = zero_pack<T, V>(); }
-                const T hy_l = left_of_tile(__shfl_up(h1[1].v[V - 1], 1)), hz_l = left_of_tile(__shfl_up(h1[2].v[V - 1], 1));
+                const T hy_l = left_of_tile(lane_below(h1[1].v[V - 1])), hz_l = left_of_tile(lane_below(h1[2].v[V - 1]));
                 const int km = k - 1;
                 const bool st = own && kl - 1 < ke;
                 P d2[3] = {d1_km[0], d1_km[1], d1_km[2]};
@@ -497,7 +517,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             if (do_d && kl >= kb + 2) {
                 const T* up = slot(e2s, eprev, w_up);                // E2(k-2) of the row above, published one iteration ago
                 const P ex_jp = lds_ld<T, V>(up), ez_jp = lds_ld<T, V>(up + TW);
-                const T ey_r = right_of_tile(__shfl_down(e2_km2[1].v[0], 1)), ez_r = right_of_tile(__shfl_down(e2_km2[2].v[0], 1));
+                const T ey_r = right_of_tile(lane_above(e2_km2[1].v[0])), ez_r = right_of_tile(lane_above(e2_km2[2].v[0]));
                 const int km2 = k - 2;
                 const bool bl_lt = km2 >= 0 && km2 < Nz;
                 P b2[3] = {b1_km2[0], b1_km2[1], b1_km2[2]};
