@@ -275,6 +275,7 @@ struct fdtd3d_engine {
     virtual int step_pair_part(int n, int part, hipStream_t s) = 0;
     virtual int pair_shape(int chunk, int rows) = 0;
     virtual bool pair_auto() = 0;
+    virtual bool pair_capable() = 0;
     virtual void pair_give_up() = 0;
     virtual void pair_info(int out[4]) = 0;
     virtual void pair_layout(int out[4]) = 0;
@@ -1340,11 +1341,15 @@ struct Engine3 : fdtd3d_engine {
     // fdtd3d_step takes its steps two at a time when that is the faster way: a FUSED engine holding the whole grid,
     // and enough cells that workgroups of 16 waves x long chunks still fill the chip (FDTD_PAIR=0/1 overrides)
     bool pair_off = false;            // a two-step launch could not get its scratch memory: fdtd3d_step stays with single steps
-    bool pair_auto() override {
-        if (!fused || d.z_lo != 0 || d.z_hi != d.Nz || pair_off) return false;
+    // whether two-step launches can run on this engine at all (whole grid or slab)
+    bool pair_capable() override {
+        if (!fused || pair_off) return false;
         for (int m = 0; m < 2; ++m) for (int c = 0; c < 3; ++c) for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd)
             if (phSize[m][c][ax][sd] >= ((size_t)1 << 31)) return false;       // the kernel indexes the CPML state with 32 bits
-        if (!pair_scratch_ok()) return false;
+        return pair_scratch_ok();
+    }
+    bool pair_auto() override {
+        if (d.z_lo != 0 || d.z_hi != d.Nz || !pair_capable()) return false;
         if (const char* e = getenv("FDTD_PAIR")) return atoi(e) != 0;
         bool pml = false;
         for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd) pml = pml || np[ax][sd] != 0;
@@ -1677,6 +1682,7 @@ int fdtd3d_pair_info(fdtd3d_handle h, int out[4]) {
     h->pair_info(out);
     return FDTD_OK;
 }
+int fdtd3d_pair_capable(fdtd3d_handle h) { return (h && h->pair_capable()) ? 1 : 0; }
 int fdtd3d_pair_layout(fdtd3d_handle h, int out[4]) {
     if (!h || !out) return fail(FDTD_ERR_ARG, "null argument");
     h->pair_layout(out);

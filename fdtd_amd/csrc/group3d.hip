@@ -15,6 +15,13 @@ using namespace fdtd;
 struct fdtd3d_group {
     fdtd3d_desc d{};
     bool fused = false;
+    // Two steps per launch: the slabs then OVERLAP by one layer either side of every cut (slab r stores the layers
+    // [lo[r]-1, hi[r]+1) and answers for [lo[r], hi[r])), because the two-step kernel recomputes its halos from what a
+    // slab stores and is exact only two planes away from a cut; after every launch the two planes beyond each cut are
+    // overwritten with the neighbour's exact ones (step_pairs below).
+    bool pairs = false;
+    std::vector<int> lo, hi;                    // the layers each slab answers for
+    std::vector<int> xchg_ids;                  // arrays whose planes cross a cut after a launch
     std::vector<fdtd3d_handle> member;          // bottom slab first
     std::vector<int> device;
     // per member: the stream its kernels run on, and the streams that carry its planes to the slab
@@ -30,6 +37,7 @@ struct fdtd3d_group {
     //   sent_up[r]    on up[r]:   r's top B/H planes have arrived in the low ghost of slab r+1
     // Slab r-1 waits for sent_down[r], slab r+1 for sent_up[r].
     std::vector<hipEvent_t> edge_done, top_done, sent_down, sent_up;
+    bool exchanged_once = false;                // overlapping slabs: the arrival events have been recorded at least once
     // The slab every stream and event was created for, so that record() can refuse a pair that would
     // sit on different devices on a multi-GPU node -- also when all slabs share one device, where HIP
     // itself would accept it.
@@ -82,6 +90,93 @@ int copy_planes(fdtd3d_group* g, int src, int which_src, int dst, int which_dst,
         if (nb != nb2) return fail(FDTD_ERR_STATE, "group: ghost planes of slabs %d and %d differ in size", src, dst);
         if (g->device[src] == g->device[dst]) FDTD_HIP(hipMemcpyAsync(to, from, nb, hipMemcpyDeviceToDevice, stream));
         else FDTD_HIP(hipMemcpyPeerAsync(to, g->device[dst], from, g->device[src], nb, stream));
+    }
+    return FDTD_OK;
+}
+
+// ---- two steps per launch ------------------------------------------------------------------------------------
+// `count` planes of every exchanged array from global plane k of slab `src` into the same planes of slab `dst`
+// (current buffers of both), on `stream` (a stream of the source's device, which must be current).
+int copy_cut_planes(fdtd3d_group* g, int src, int dst, int k, hipStream_t stream) {
+    for (int id : g->xchg_ids) {
+        void *from = nullptr, *to = nullptr;
+        size_t nb = 0, nb2 = 0;
+        if (int rc = fdtd3d_planes(g->member[src], id, k, 2, &from, &nb)) return rc;
+        if (int rc = fdtd3d_planes(g->member[dst], id, k, 2, &to, &nb2)) return rc;
+        if (nb != nb2) return fail(FDTD_ERR_STATE, "group: planes of array %d differ in size between slabs %d and %d", id, src, dst);
+        if (g->device[src] == g->device[dst]) FDTD_HIP(hipMemcpyAsync(to, from, nb, hipMemcpyDeviceToDevice, stream));
+        else FDTD_HIP(hipMemcpyPeerAsync(to, g->device[dst], from, g->device[src], nb, stream));
+    }
+    return FDTD_OK;
+}
+// After the launches that produced the planes next to the cuts (recorded as edge_done): the two planes below every cut
+// go up, the two above it go down.  The copies run on the copy streams, beside whatever the launch streams do next
+// (the bulk of a two-step launch neither reads the buffers the planes land in nor writes those planes).
+int exchange_cut_planes(fdtd3d_group* g) {
+    const int R = (int)g->member.size();
+    int rc;
+    for (int r = 0; r + 1 < R; ++r) {
+        const int cut = g->hi[r];
+        {
+            DeviceScope scope(g->device[r]);
+            FDTD_HIP(hipStreamWaitEvent(g->up[r], g->edge_done[r], 0));
+            FDTD_HIP(hipStreamWaitEvent(g->up[r], g->edge_done[r + 1], 0));
+            if ((rc = copy_cut_planes(g, r, r + 1, cut - 2, g->up[r]))) return rc;
+            if ((rc = record(g, g->sent_up[r], g->up[r]))) return rc;
+        }
+        {
+            DeviceScope scope(g->device[r + 1]);
+            FDTD_HIP(hipStreamWaitEvent(g->down[r + 1], g->edge_done[r + 1], 0));
+            FDTD_HIP(hipStreamWaitEvent(g->down[r + 1], g->edge_done[r], 0));
+            if ((rc = copy_cut_planes(g, r + 1, r, cut, g->down[r + 1]))) return rc;
+            if ((rc = record(g, g->sent_down[r + 1], g->down[r + 1]))) return rc;
+        }
+    }
+    return FDTD_OK;
+}
+// A slab's next launch reads the planes that arrived and overwrites (two launches on) the ones that left.
+int wait_for_cut_planes(fdtd3d_group* g, int r) {
+    const int R = (int)g->member.size();
+    if (!g->exchanged_once) return FDTD_OK;
+    if (r > 0) { FDTD_HIP(hipStreamWaitEvent(g->run[r], g->sent_up[r - 1], 0)); FDTD_HIP(hipStreamWaitEvent(g->run[r], g->sent_down[r], 0)); }
+    if (r + 1 < R) { FDTD_HIP(hipStreamWaitEvent(g->run[r], g->sent_down[r + 1], 0)); FDTD_HIP(hipStreamWaitEvent(g->run[r], g->sent_up[r], 0)); }
+    return FDTD_OK;
+}
+// Steps n and n+1 in one launch per slab, cut in two (fdtd3d_pair_part): the three planes at either end first, the
+// exchange is started, the bulk runs while the planes travel.
+int step_pair(fdtd3d_group* g, int n) {
+    const int R = (int)g->member.size();
+    int rc;
+    for (int r = 0; r < R; ++r) {
+        DeviceScope scope(g->device[r]);
+        if ((rc = wait_for_cut_planes(g, r))) return rc;
+        if ((rc = fdtd3d_pair_part(g->member[r], n, FDTD3D_PART_EDGE, g->run[r]))) return rc;
+        if ((rc = record(g, g->edge_done[r], g->run[r]))) return rc;
+    }
+    if ((rc = exchange_cut_planes(g))) return rc;
+    g->exchanged_once = true;
+    for (int r = 0; r < R; ++r) {
+        DeviceScope scope(g->device[r]);
+        if ((rc = fdtd3d_pair_part(g->member[r], n, FDTD3D_PART_INTERIOR, g->run[r]))) return rc;
+    }
+    return FDTD_OK;
+}
+// One step on overlapping slabs: the one-step kernel over everything a slab stores, then the same exchange.
+int step_single_overlapping(fdtd3d_group* g, int n) {
+    const int R = (int)g->member.size();
+    int rc;
+    for (int r = 0; r < R; ++r) {
+        DeviceScope scope(g->device[r]);
+        if ((rc = wait_for_cut_planes(g, r))) return rc;
+        if ((rc = fdtd3d_fused(g->member[r], n, FDTD3D_PART_ALL, g->run[r]))) return rc;
+        if ((rc = record(g, g->edge_done[r], g->run[r]))) return rc;
+    }
+    if ((rc = exchange_cut_planes(g))) return rc;
+    g->exchanged_once = true;
+    // probes sample the layers a slab answers for, which the exchange does not touch
+    for (int r = 0; r < R; ++r) {
+        DeviceScope scope(g->device[r]);
+        if ((rc = fdtd3d_probe_record(g->member[r], g->run[r]))) return rc;
     }
     return FDTD_OK;
 }
@@ -174,18 +269,47 @@ int build_group(fdtd3d_group* g, const fdtd3d_desc* desc, int n_slabs, const int
     FDTD_HIP(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(FDTD_ERR_HIP, "no HIP device visible");
     const int base = desc->Nz / n_slabs, extra = desc->Nz % n_slabs;
-    int lo = 0;
+    for (int r = 0, lo = 0; r < n_slabs; ++r) {
+        g->lo.push_back(lo);
+        lo += base + (r < extra ? 1 : 0);
+        g->hi.push_back(lo);
+    }
+    // Two steps per launch where they pay (as fdtd3d_step decides for a whole grid: enough cells per slab, or FDTD_PAIR=1
+    // in the environment; FDTD_PAIR=0: never) and where the slabs allow them: FUSED storage, every slab at least two
+    // layers thick, every cut clear of the z-face CPML layers by the planes that cross it (their state is not exchanged).
+    bool pml = false;
+    for (int q = 0; q < 6; ++q) pml = pml || desc->n_pml[q] != 0;
+    const char* env_pair = getenv("FDTD_PAIR");
+    const double slab_cells = (double)desc->Nx * desc->Ny * base, edge = pml ? 448.0 : 384.0;
+    bool want_pairs = g->fused && n_slabs > 1 && (env_pair ? atoi(env_pair) != 0 : slab_cells >= edge * edge * edge);
+    for (int r = 0; r < n_slabs && want_pairs; ++r) {
+        if (g->hi[r] - g->lo[r] < 2) want_pairs = false;
+        const int cut = g->lo[r];
+        if (r > 0 && !(cut - 2 > desc->n_pml[4] + 1 && cut + 2 < desc->Nz - desc->n_pml[5] - 1)) want_pairs = false;
+    }
     for (int r = 0; r < n_slabs; ++r) {
         const int dev = devices ? devices[r] : r % ndev;
         if (dev < 0 || dev >= ndev) return fail(FDTD_ERR_ARG, "group: slab %d asks for device %d, %d visible", r, dev, ndev);
         fdtd3d_desc md = *desc;
-        md.z_lo = lo;
-        md.z_hi = lo + base + (r < extra ? 1 : 0);
+        md.z_lo = want_pairs ? std::max(0, g->lo[r] - 1) : g->lo[r];
+        md.z_hi = want_pairs ? std::min(desc->Nz, g->hi[r] + 1) : g->hi[r];
         md.device = dev;
-        lo = md.z_hi;
         g->member.push_back(nullptr);
         g->device.push_back(dev);
         if (int rc = fdtd3d_create(&md, &g->member.back())) return rc;
+        if (want_pairs && !fdtd3d_pair_capable(g->member.back()))
+            return fail(FDTD_ERR_STATE, "group: slab %d cannot take two steps per launch (CPML state or scratch memory beyond 32-bit indexing); set FDTD_PAIR=0", r);
+    }
+    g->pairs = want_pairs;
+    if (g->pairs) {
+        // what crosses a cut: D, B and the x- and y-face CPML state of both families
+        for (int c = 0; c < 3; ++c) g->xchg_ids.push_back(FDTD3D_DX + c);
+        for (int c = 0; c < 3; ++c) g->xchg_ids.push_back(FDTD3D_BX + c);
+        for (int base_id : {(int)FDTD3D_PHI_E, (int)FDTD3D_PHI_M})
+            for (int comp = 0; comp < 3; ++comp) for (int axis = 0; axis < 2; ++axis) for (int side = 0; side < 2; ++side) {
+                const int id = base_id + (comp * 3 + axis) * 2 + side;
+                if (axis != comp && fdtd3d_array_size(g->member[0], id) > 0) g->xchg_ids.push_back(id);
+            }
     }
     // direct copies between the devices of neighbouring slabs (over xGMI); where the driver refuses,
     // hipMemcpyPeerAsync still works, staged by the runtime
@@ -274,16 +398,33 @@ fdtd3d_handle fdtd3d_group_member(fdtd3d_group_handle g, int r) {
 
 int fdtd3d_group_step(fdtd3d_group_handle g, int n0, int count) {
     if (!g) return fail(FDTD_ERR_ARG, "null group");
-    for (int n = n0; n < n0 + count; ++n) {
-        int rc;
-        if (g->member.size() == 1) {
-            DeviceScope scope(g->device[0]);
-            rc = fdtd3d_step(g->member[0], n, 1, g->run[0]);
-        } else {
-            rc = g->fused ? step_fused(g, n) : step_halves(g, n);
-        }
-        if (rc) return rc;
+    if (g->member.size() == 1) {
+        DeviceScope scope(g->device[0]);
+        return fdtd3d_step(g->member[0], n0, count, g->run[0]);        // (pairs its steps by itself where that pays)
     }
+    if (g->pairs) {
+        // a probe is sampled after every single step, and the values after the first step of a two-step launch never
+        // reach memory: groups with probes take single steps
+        bool probed = false;
+        for (fdtd3d_handle m : g->member) {
+            int ns = 0, np = 0;
+            if (int rc = fdtd3d_probe_read(m, nullptr, 0, &ns, &np)) return rc;
+            probed = probed || np > 0;
+        }
+        for (int n = n0; n < n0 + count;) {
+            if (!probed && n + 2 <= n0 + count) { if (int rc = step_pair(g, n)) return rc; n += 2; }
+            else { if (int rc = step_single_overlapping(g, n)) return rc; ++n; }
+        }
+        return FDTD_OK;
+    }
+    for (int n = n0; n < n0 + count; ++n)
+        if (int rc = g->fused ? step_fused(g, n) : step_halves(g, n)) return rc;
+    return FDTD_OK;
+}
+int fdtd3d_group_pairs(fdtd3d_group_handle g) { return (g && g->pairs) ? 1 : 0; }
+int fdtd3d_group_bounds(fdtd3d_group_handle g, int r, int* lo, int* hi) {
+    if (!g || r < 0 || r >= (int)g->member.size() || !lo || !hi) return fail(FDTD_ERR_ARG, "group_bounds: bad argument");
+    *lo = g->lo[r]; *hi = g->hi[r];
     return FDTD_OK;
 }
 
@@ -315,8 +456,10 @@ int fdtd3d_group_fill_reference_materials(fdtd3d_group_handle g) {
 }
 int fdtd3d_group_observe_accumulate(fdtd3d_group_handle g, double weight, int reset) {
     if (!g) return fail(FDTD_ERR_ARG, "null group");
-    for (size_t r = 0; r < g->member.size(); ++r)
+    for (size_t r = 0; r < g->member.size(); ++r) {
+        if (g->pairs) { DeviceScope scope(g->device[r]); if (int rc = wait_for_cut_planes(g, (int)r)) return rc; }
         if (int rc = fdtd3d_observe_accumulate(g->member[r], weight, reset, g->run[r])) return rc;
+    }
     return FDTD_OK;
 }
 int fdtd3d_group_observe_rms(fdtd3d_group_handle g, double* host, size_t n) {
@@ -336,8 +479,9 @@ int fdtd3d_group_step_observed(fdtd3d_group_handle g, int n0, int count, double 
         return fdtd3d_step_observed(g->member[0], n0, count, weight, window, g->run[0]);
     }
     for (int n = n0; n < n0 + count; ++n) {
-        if (int rc = g->fused ? step_fused(g, n) : step_halves(g, n)) return rc;
+        if (int rc = g->pairs ? step_single_overlapping(g, n) : (g->fused ? step_fused(g, n) : step_halves(g, n))) return rc;
         for (size_t r = 0; r < g->member.size(); ++r) {
+            if (g->pairs) { DeviceScope scope(g->device[r]); if (int rc = wait_for_cut_planes(g, (int)r)) return rc; }      // the top layer's cells look at the plane above
             if (int rc = fdtd3d_observe_accumulate(g->member[r], weight, n % window == 0, g->run[r])) return rc;
             if ((n + 1) % window == 0) if (int rc = fdtd3d_observe_keep_window(g->member[r])) return rc;
         }
@@ -346,8 +490,10 @@ int fdtd3d_group_step_observed(fdtd3d_group_handle g, int n0, int count, double 
 }
 int fdtd3d_group_observe_frame(fdtd3d_group_handle g, double* ex_center, double* e_mag, size_t n) {
     if (!g) return fail(FDTD_ERR_ARG, "null group");
-    for (size_t r = 0; r < g->member.size(); ++r)
+    for (size_t r = 0; r < g->member.size(); ++r) {
+        if (g->pairs) { DeviceScope scope(g->device[r]); if (int rc = wait_for_cut_planes(g, (int)r)) return rc; }
         if (int rc = fdtd3d_observe_frame(g->member[r], ex_center, e_mag, n, g->run[r])) return rc;
+    }
     return FDTD_OK;
 }
 

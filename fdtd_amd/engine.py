@@ -426,13 +426,23 @@ class EngineGroup3D:
         _check(lib().fdtd3d_group_observe_frame(self.h, a.ctypes.data_as(_dp), b.ctypes.data_as(_dp), C.c_size_t(n)), "fdtd3d_group_observe_frame")
         return a, b
 
-    def sumsq(self, id_: int) -> float:
+    def _own_reductions(self, id_: int):
+        """Per slab, (sum of squares, checksum) over the layers it answers for (slabs that take two steps per launch
+        store one layer more either side of a cut)."""
         self.sync()
-        return sum(m.sumsq(id_) for m in self.members)
+        Nz = self.N[2]
+        return [m.reduce_range(id_, lo, Nz + 1 if hi == Nz else hi) for m, (lo, hi) in zip(self.members, self.bounds())]
+
+    def sumsq(self, id_: int) -> float:
+        return sum(ss for ss, _ in self._own_reductions(id_))
 
     def checksum(self, id_: int) -> int:
-        self.sync()
-        return sum(m.checksum(id_) for m in self.members) % 2 ** 64
+        return sum(cs for _, cs in self._own_reductions(id_)) % 2 ** 64
+
+    @property
+    def pairs(self) -> bool:
+        """Whether step() takes two steps per launch (overlapping slabs)."""
+        return bool(lib().fdtd3d_group_pairs(self.h))
 
     def owner(self, k: int) -> "_Member":
         """The member that owns cell layer k (the last one also plane Nz)."""

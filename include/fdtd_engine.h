@@ -176,6 +176,9 @@ int fdtd3d_pair_scratch_fits(long long workgroups, int waves_per_group, int prec
 /* out = { 1 if fdtd3d_step takes its steps two per launch on this engine, planes per workgroup,
  *         waves per workgroup, elements per lane } of the two-step kernel. */
 int fdtd3d_pair_info(fdtd3d_handle h, int out[4]);
+/* 1 if two-step launches can run on this engine at all, whole grid or slab (FUSED storage, CPML state and scratch
+ * memory within what the kernel indexes with 32 bits), else 0. */
+int fdtd3d_pair_capable(fdtd3d_handle h);
 /* out = { x tiles per row, lanes of tile 0 that hold the first columns of a row when that tile holds both ends
  *         of it (0: the tiles lie in a row), first column of its other lanes, tiles per run handed to one XCD
  *         (0: tiles are taken as dealt) } of the two-step kernel's next launch.  No counterpart in the reference. */
@@ -348,6 +351,16 @@ typedef struct fdtd3d_group* fdtd3d_group_handle;
 int fdtd3d_group_create(const fdtd3d_desc* desc, int n_slabs, const int* devices, fdtd3d_group_handle* out);
 int fdtd3d_group_destroy(fdtd3d_group_handle g);
 int fdtd3d_group_slabs(fdtd3d_group_handle g);
+/* FUSED groups of slabs large enough for it (the sizes from which fdtd3d_step pairs its steps, counted per slab;
+ * FDTD_PAIR=0/1 in the environment overrides) take TWO steps per launch as well: their slabs then overlap by one
+ * layer either side of every cut (slab r stores [lo-1, hi+1) and answers for [lo, hi), see the note on overlapping
+ * slabs above), every slab's launch is cut into the planes next to its cuts and the bulk, and after the first part
+ * the two planes beyond each cut are copied over from the neighbour while the bulk runs.  Needs every slab two
+ * layers thick and every cut clear of the z-face CPML layers; otherwise, and for groups with probes (sampled after
+ * every single step), the one-step choreography runs.  fdtd3d_group_pairs() tells (1/0); fdtd3d_group_bounds() gives
+ * the layers [lo, hi) slab r answers for (what its handle stores may be one layer more either side). */
+int fdtd3d_group_pairs(fdtd3d_group_handle g);
+int fdtd3d_group_bounds(fdtd3d_group_handle g, int r, int* lo, int* hi);
 /* Every event of a group is recorded through a check that event and stream were created for the same
  * slab (HIP refuses to record an event on a stream of another device; with all slabs on one device
  * it would not notice).  A mismatch makes fdtd3d_group_step() fail with FDTD_ERR_STATE. */

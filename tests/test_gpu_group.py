@@ -16,6 +16,15 @@ from tests.test_gpu_parity import FIX3D
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[None, "1"], ids=["one-step", "two-step"])
+def pair_env(request, monkeypatch):
+    """Default: grids this small step one step per launch.  FDTD_PAIR=1: FUSED groups whose cuts allow it take two
+    steps per launch on overlapping slabs (and single engines pair their steps too)."""
+    if request.param is not None:
+        monkeypatch.setenv("FDTD_PAIR", request.param)
+    return request.param
+
+
 def group_from_meta(meta, prec, n_slabs, mode, **kw):
     return E.EngineGroup3D(meta["N"], meta["npml"], (meta["dx"], meta["dy"], meta["dz"]), meta["dt"], meta["mu0"],
                            meta["k_Jx"], meta["steps"], n_slabs, precision=prec, mode=mode, **kw)
@@ -24,9 +33,11 @@ def group_from_meta(meta, prec, n_slabs, mode, **kw):
 @pytest.mark.parametrize("name", FIX3D)
 @pytest.mark.parametrize("mode", [E.MODE_FULL, E.MODE_LEAN, E.MODE_FUSED])
 @pytest.mark.parametrize("n_slabs", [2, 3])
-def test_group_fp64_equals_reference_golden(name, mode, n_slabs):
+def test_group_fp64_equals_reference_golden(name, mode, n_slabs, pair_env):
     meta, ins, outs, _ = util.load_fixture(name)
     g = group_from_meta(meta, 64, n_slabs, mode)
+    if name in ("g1_3d_cpml", "g2_3d_cavity"):           # (their cuts are clear of the z layers)
+        assert g.pairs == (pair_env == "1" and mode == E.MODE_FUSED)
     util.feed(g, ins)
     got = util.run_snapshots(g, meta, outs)
     for key, want in outs.items():
@@ -35,7 +46,7 @@ def test_group_fp64_equals_reference_golden(name, mode, n_slabs):
 
 
 @pytest.mark.parametrize("mode", [E.MODE_LEAN, E.MODE_FUSED])
-def test_group_fp32_equals_twin_and_single_engine(mode):
+def test_group_fp32_equals_twin_and_single_engine(mode, pair_env):
     meta, ins, outs, _ = util.load_fixture("g3_3d_hetero")
     g = group_from_meta(meta, 32, 4, mode)
     tw = util.twin3d_from_meta(meta, 32)
@@ -54,7 +65,7 @@ def test_group_fp32_equals_twin_and_single_engine(mode):
         assert g.sumsq(id_) == pytest.approx(one.sumsq(id_), rel=1e-12)
 
 
-def test_group_observables_and_probe():
+def test_group_observables_and_probe(pair_env):
     meta, ins, outs, extra = util.load_fixture("g2_3d_cavity")
     g = group_from_meta(meta, 64, 3, E.MODE_FUSED)
     tw = util.twin3d_from_meta(meta, 64)
@@ -76,7 +87,7 @@ def test_group_observables_and_probe():
 
 
 @pytest.mark.parametrize("seed", range(12))
-def test_group_random_configurations_equal_twin(seed):
+def test_group_random_configurations_equal_twin(seed, pair_env):
     from tests.test_gpu_fused import _random_case
     rng = np.random.default_rng(4000 + seed)
     N, npml, prec, has_mu, rows, chunk = _random_case(rng)
@@ -114,7 +125,7 @@ def test_group_random_configurations_equal_twin(seed):
 
 
 @pytest.mark.parametrize("slabs,mode", [(5, E.MODE_FUSED), (16, E.MODE_FUSED), (8, E.MODE_LEAN), (16, E.MODE_FULL)])
-def test_group_many_slabs_midsize(slabs, mode):
+def test_group_many_slabs_midsize(slabs, mode, pair_env):
     """300 x 100 x 130 cells cut into up to 16 slabs (kernels long enough for the copies to overlap them),
     30 steps in two calls: same checksums as one engine on the whole grid."""
     from fdtd_amd import setup as fs
@@ -186,3 +197,41 @@ def test_group_events_are_recorded_on_streams_of_their_own_slab(monkeypatch):
             g.close()
     finally:
         L.fdtd3d_group_debug_misown_events(0)
+
+
+def test_group_two_step_launches_with_observed_steps_and_resume(monkeypatch):
+    """Overlapping slabs: pairs, a single step, pairs again, observed steps (one step per launch there), a download of
+    everything, an upload into a fresh group and more pairs -- every array equals the twin's throughout."""
+    monkeypatch.setenv("FDTD_PAIR", "1")
+    meta, ins, _, _ = util.load_fixture("g1_3d_cpml")
+    g = group_from_meta(meta, 32, 3, E.MODE_FUSED)
+    assert g.pairs
+    tw = util.twin3d_from_meta(meta, 32)
+    util.feed(g, ins)
+    util.feed(tw, ins)
+    g.step(0, 7)
+    tw.step(0, 7)
+    g.step_observed(7, 6, 0.1, 4)
+    for n in range(7, 13):
+        tw.step(n, 1)
+        tw.observe_accumulate(0.1, n % 4 == 0)
+        if (n + 1) % 4 == 0:
+            kept = tw.observe_rms().copy()
+    util.assert_equal_arrays(g.observe_rms_window(), kept, "window completed at step 11")
+    util.assert_equal_arrays(g.observe_rms(), tw.observe_rms(), "window being accumulated after step 12")
+    state = {id_: g.get(id_) for id_ in po.FIELDS3D + po.ALL_PHI3D if g.size(id_)}
+    for id_, a in state.items():
+        util.assert_equal_arrays(a, tw.get(id_), f"array {id_} after 13 steps")
+    g.close()
+    g2 = group_from_meta(meta, 32, 2, E.MODE_FUSED)
+    assert g2.pairs
+    util.feed(g2, ins)
+    for id_, a in state.items():
+        if id_ not in (E.EX, E.EY, E.EZ, E.HX, E.HY, E.HZ):
+            g2.set(id_, a)
+    g2.step(13, 8)
+    tw.step(13, 8)
+    for id_ in po.FIELDS3D + po.ALL_PHI3D:
+        if g2.size(id_):
+            util.assert_equal_arrays(g2.get(id_), tw.get(id_), f"array {id_} after the resumed run")
+    g2.close()
