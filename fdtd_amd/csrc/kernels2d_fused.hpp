@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(kLanes * kStack2D) k2_fused(const K2F<T> a) {
         hx = field_of<T, V>(bxo, a.mu0, flag, ap->H1[0] + ro, ap->C1 + ro, ap->C2 + ro, ap->C3 + ro, lo);
         P hz = field_of<T, V>(bzo, a.mu0, flag, ap->H1[1] + ro, ap->C1 + ro, ap->C2 + ro, ap->C3 + ro, lo);
         if (!valid) { hx = zero_pack<T, V>(); hz = hx; }
-        T hz_l = __shfl_up(hz.v[V - 1], 1);
+        T hz_l = lane_below(hz.v[V - 1]);
         if (lane == 0) {
             hz_l = (T)0;
             if (c0 > 0) {
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(kLanes * kStack2D) k2_fused(const K2F<T> a) {
         }
 
         // ---------------------------------------------------------------- row k-1: B_new, H_new
-        const T e_r = __shfl_down(e_km.v[0], 1);          // taken with all lanes active: lane 62 needs lane 63's value
+        const T e_r = lane_above(e_km.v[0]);          // taken with all lanes active: lane 62 needs lane 63's value
         if (k > kb) {
             asm volatile("" : "+s"(ap));
             const int km = k - 1;                        // km < Nz always: k <= Nz

@@ -74,13 +74,13 @@ struct K3 {
 
 template <typename T, int V>
 __device__ __forceinline__ T left_of(const Pack<T, V>& x, const T* p, int i0, int lane) {
-    T l = __shfl_up(x.v[V - 1], 1);
+    T l = lane_below(x.v[V - 1]);
     if (lane == 0) l = (i0 > 0) ? p[-1] : (T)0;
     return l;
 }
 template <typename T, int V>
 __device__ __forceinline__ T right_of(const Pack<T, V>& x, const T* p, int i0, int lane, int px) {
-    T r = __shfl_down(x.v[0], 1);
+    T r = lane_above(x.v[0]);
     if (lane == kLanes - 1) r = (i0 + V < px) ? p[V] : (T)0;
     return r;
 }
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(256) k3_half_e(const K3<T> a) {
         P ex = zero_pack<T, V>(), ey = ex, ez = ex;
         if (!LEAN) { ex = ldv<T, V>(a.eps[0] + idx); ey = ldv<T, V>(a.eps[1] + idx); ez = ldv<T, V>(a.eps[2] + idx); }
 
-        T hy_l = __shfl_up(hy.v[V - 1], 1), hz_l = __shfl_up(hz.v[V - 1], 1);
+        T hy_l = lane_below(hy.v[V - 1]), hz_l = lane_below(hz.v[V - 1]);
         if (lane == 0) {
             hy_l = i0 > 0 ? load_h1<T, MU, LEAN>(a, 1, idx - 1) : (T)0;
             hz_l = i0 > 0 ? load_h1<T, MU, LEAN>(a, 2, idx - 1) : (T)0;
@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(256) k3_half_h(const K3<T> a) {
         P mx = zero_pack<T, V>(), my = mx, mz = mx;
         if (MU && !LEAN) { mx = ldv<T, V>(a.mu[0] + idx); my = ldv<T, V>(a.mu[1] + idx); mz = ldv<T, V>(a.mu[2] + idx); }
 
-        T ey_r = __shfl_down(ey.v[0], 1), ez_r = __shfl_down(ez.v[0], 1);
+        T ey_r = lane_above(ey.v[0]), ez_r = lane_above(ez.v[0]);
         if (lane == kLanes - 1) {
             ey_r = i0 + V < px ? load_e1<T, LEAN>(a, 1, idx + V) : (T)0;
             ez_r = i0 + V < px ? load_e1<T, LEAN>(a, 2, idx + V) : (T)0;

@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(kLanes * MAXW) __attribute__((amdgpu_waves_per
             else { hx_jm = divide<T, V>(b0j, a.mu0); hz_jm = divide<T, V>(b2j, a.mu0); }
         }
         if (!EARLY) { request_d_eps(); request_left(); }
-        T hy_l = __shfl_up(hy.v[V - 1], 1), hz_l = __shfl_up(hz.v[V - 1], 1);
+        T hy_l = lane_below(hy.v[V - 1]), hz_l = lane_below(hz.v[V - 1]);
         if (EARLY && c0 > 0) { b1l = nb_of(48); b2l = nb_of(49); if (MU) { m1l = nb_of(50); m2l = nb_of(51); } }
         if (lane == 0) {
             hy_l = c0 > 0 ? b1l / m1l : (T)0;
@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(kLanes * MAXW) __attribute__((amdgpu_waves_per
             const size_t rb = ro - sz;
             const int klm = kl - 1, km = k - 1;
             const bool bl_lt = km < Nz, bl_in = km >= 1 && km < Nz;
-            T ey_r = __shfl_down(en_km[1].v[0], 1), ez_r = __shfl_down(en_km[2].v[0], 1);
+            T ey_r = lane_above(en_km[1].v[0]), ez_r = lane_above(en_km[2].v[0]);
             if (lane == kLanes - 1) { ey_r = eye_km; ez_r = eze_km; }
             const size_t pz = ((size_t)lkh * a.ny1 + j) * px + c0;
             const size_t py0 = ((size_t)klm * a.np[1][0] + lyh) * px + c0, py1 = ((size_t)klm * a.np[1][1] + lyh) * px + c0;

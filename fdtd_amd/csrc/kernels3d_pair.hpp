@@ -50,26 +50,6 @@ __device__ __forceinline__ void lds_st(T* p, const Pack<T, V>& r) {
 }
 template <typename T> __device__ __forceinline__ Pack<T, 1> lds_ld1(const T* p) { Pack<T, 1> r; r.v[0] = *p; return r; }
 
-// The value the neighbouring lane holds: lane i receives lane i-1's (`lane_below`) or lane i+1's (`lane_above`); the
-// first (last) lane keeps its own.  One data-parallel-primitive move across the whole wave (wave_shr:1 / wave_shl:1)
-// instead of a permute through the LDS unit, which the row exchanges of the kernel keep busy enough.
-template <int CTRL>
-__device__ __forceinline__ int wave_shift_bits(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false); }
-template <int CTRL, typename T>
-__device__ __forceinline__ T wave_shift(T x) {
-    if constexpr (sizeof(T) == 4) {
-        return __builtin_bit_cast(T, wave_shift_bits<CTRL>(__builtin_bit_cast(int, x)));
-    } else {
-        static_assert(sizeof(T) == 8, "32- or 64-bit values");
-        struct Two { int lo, hi; } t = __builtin_bit_cast(Two, x);
-        t.lo = wave_shift_bits<CTRL>(t.lo);
-        t.hi = wave_shift_bits<CTRL>(t.hi);
-        return __builtin_bit_cast(T, t);
-    }
-}
-template <typename T> __device__ __forceinline__ T lane_below(T x) { return wave_shift<0x138>(x); }
-template <typename T> __device__ __forceinline__ T lane_above(T x) { return wave_shift<0x130>(x); }
-
 // d +- c * curl with a wave-uniform coefficient (the plain update between CPML layers); `skip0` leaves
 // the first element alone (tangential component on the wall column i = 0)
 template <int SIGN, typename T, int V>
