@@ -148,7 +148,7 @@ def stamped_traffic(eng, mode_name: str, dom: str, applies: bool):
     if not applies:
         return None, "no PMC pass for this configuration"
     from fdtd_amd.engine import kernel_source_digest
-    path = os.path.join(ROOT, "profiles", f"r2_traffic_1024_{mode_name}.json")
+    path = os.path.join(ROOT, "profiles", f"r3_traffic_1024_{mode_name}.json")
     try:
         with open(path) as f:
             rec = json.load(f)

@@ -34,6 +34,6 @@ t0 = time.perf_counter()
 g.step(warm, steps)
 g.sync()
 el = time.perf_counter() - t0
-print(f"{n_slabs} slab(s) on {min(ndev, n_slabs)} GPU(s), {edge}x{edge}x{Nz}, mode {mode}: {el / steps * 1e3:.3f} ms/step, "
+print(f"{n_slabs} slab(s) on {min(ndev, n_slabs)} GPU(s), {edge}x{edge}x{Nz}, mode {mode}, {'two steps' if g.pairs else 'one step'} per launch: {el / steps * 1e3:.3f} ms/step, "
       f"{edge * edge * Nz * steps / el / 1e9:.2f} Gcell/s, checksum Dx {g.checksum(E.DX)}, "
       f"gaps GiB {[ [round(v, 2) for v in m.spread_gaps()] for m in g.members]}", flush=True)
