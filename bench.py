@@ -217,10 +217,35 @@ def _timed_steps(torch, eng, warm: int, steps: int):
     return el, dev_ms * 1e-3
 
 
-def extra_legs(torch, scale: str):
+def extra_legs_in_children(scale: str):
+    """Every secondary leg in a process of its own, one after the other (this process has released its engine): the
+    step time of these kernels depends on where their arrays lie in physical memory, and a process that has held and
+    released a hundred GB before does not get the layout a fresh one gets (measured: the 2-D legs 5-10 % slower when
+    run inside the process that had timed the headline)."""
+    import subprocess
+    out = {}
+    for name in EXTRA_LEGS[scale]:
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--extra-leg", name, "--extra-scale", scale], cwd=ROOT,
+                               capture_output=True, text=True, timeout=280)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[name] = {"error": f"leg exited with status {r.returncode}: {r.stderr[-300:]}"}
+            else:
+                out.update(json.loads(lines[-1]))
+        except Exception as e:          # noqa: BLE001 -- reported in the line
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+EXTRA_LEGS = {"full": ["fp64_1024", "cavity_512", "fdtd2d_8192", "fdtd2d_8192_dispersive_everywhere"],
+              "small": ["fp64_small", "cavity_small", "fdtd2d_small", "fdtd2d_small_dispersive_everywhere"]}
+
+
+def extra_legs(torch, scale: str, only=None):
     """Secondary measurements for the one JSON line (N = 1 only, a few seconds each, after the headline engine has
     been released).  `scale` = "full": the sizes the configurations are quoted on; "small": the same code on small
-    grids (tests).  A leg that fails reports its error instead of taking the headline down with it."""
+    grids (tests).  `only`: just that leg.  A leg that fails reports its error instead of taking the headline down with it."""
     import numpy as np
     import fdtd_amd
     from fdtd_amd import engine as E
@@ -232,6 +257,8 @@ def extra_legs(torch, scale: str):
     out = {}
 
     def leg3d(name, N, npml, precision, has_mu, dipole, warm, steps, words, note):
+        if only is not None and name != only:
+            return
         try:
             n_total = warm + steps
             eng = fdtd_amd.Engine3D(N, npml, d, dt, K["mu0"], N[2] // 2 if dipole else 20, n_total, precision=precision,
@@ -269,6 +296,8 @@ def extra_legs(torch, scale: str):
             out[name] = {"error": f"{type(e).__name__}: {e}"}
 
     def leg2d(name, N, material, warm, steps):
+        if only is not None and name != only:
+            return
         try:
             dx = K["c0"] / 1.5e14 / 40
             dt2 = dx / (2 * K["c0"])
@@ -347,7 +376,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--extra-leg", default=None, help=argparse.SUPPRESS)       # one secondary leg in this process (see extra_legs_in_children)
+    ap.add_argument("--extra-scale", default="full", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.extra_leg:
+        import torch
+        torch.cuda.set_device(0)
+        print(json.dumps(extra_legs(torch, args.extra_scale, only=args.extra_leg)))
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("FDTD_BENCH_GROUP", "0") != "1":
         sys.exit(relaunch_one_process_per_gpu(args))
@@ -533,7 +570,7 @@ def main():
         extra_scale = os.environ.get("FDTD_BENCH_EXTRA", "full" if (n_edge == 1024 and mode_name == "fused") else "0")
         if world == 1 and extra_scale in ("full", "small", "1"):
             eng.close()                   # the secondary legs need the memory (fp64 at 1024^3 holds 161 GB)
-            out["extra"] = extra_legs(torch, "small" if extra_scale == "small" else "full")
+            out["extra"] = extra_legs_in_children("small" if extra_scale == "small" else "full")
         if world == 1 and os.environ.get("FDTD_BENCH_CPU", "1") != "0":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
