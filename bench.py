@@ -161,6 +161,30 @@ def stamped_traffic(eng, mode_name: str, dom: str, applies: bool):
         return None, "no PMC pass recorded"
 
 
+def live_traffic(dom: str, has_mu: bool):
+    """HBM bytes per launch of the dominant kernel measured NOW, on this box and this build: two rocprofv3 --pmc passes
+    (FETCH_SIZE, WRITE_SIZE) over a few steps of the same configuration on the non-zero state, run as child processes
+    after this process has released its engine (tools/pmc_traffic.py).  None if the profiler is not there or a pass fails."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not on PATH"
+    out = os.path.join(tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp"), "traffic.json")
+    steps = "6" if dom == "k3_pair" else "4"
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), "--out", out, "--kernels", dom, "--",
+           "tools/prof3d.py", "--mode", "fused", "--n", "1024", "--steps", steps, "--noise"] + ([] if has_mu else ["--no-mu"])
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=400)
+        if r.returncode != 0:
+            return None, f"PMC passes failed ({r.returncode}): {(r.stderr or r.stdout)[-200:]}"
+        with open(out) as f:
+            rec = json.load(f)
+        return rec["per_launch"][dom], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py as child processes (same build, same box, same configuration on the non-zero state)"
+    except Exception as e:          # noqa: BLE001 -- the stamped value stays
+        return None, f"{type(e).__name__}: {e}"
+
+
 def roofline_block(eng, mode_name, has_mu, cells_local, steps, applies_traffic, world, total_cells, el):
     """The roofline object for one engine from its launch timers (call launch_summary first: this consumes them)."""
     n_e, ms_e = eng.kernel_time(0)
@@ -193,6 +217,8 @@ def roofline_block(eng, mode_name, has_mu, cells_local, steps, applies_traffic, 
             "traffic": traffic, "traffic_source": traffic_src,
             "traffic_rate_GBs": (traffic / (t_dom * spl) / 1e9) if (traffic and t_dom > 0) else None,   # bytes really moved per second
             "traffic_frac_of_peak": (traffic / (t_dom * spl) / 1e9 / HBM_PEAK_GBS) if (traffic and t_dom > 0) else None,
+            "frac_note": "achieved/frac price the step at the reference formulation's bytes (a work rate: it exceeds 1 when the kernels move fewer "
+                         "bytes than that formulation); traffic_rate_GBs / traffic_frac_of_peak are the bytes really moved",
             "steps_per_launch": spl,
             "kernel_ms_per_launch": (ms_p / n_p) if n_p > 0 else None,
             "algorithmic_bytes_per_launch": cells_local * dom_bytes * spl, "algorithmic_bytes_per_cell": dom_bytes,
@@ -568,8 +594,19 @@ def main():
         if multi is not None:
             out["multi_gpu"] = multi
         extra_scale = os.environ.get("FDTD_BENCH_EXTRA", "full" if (n_edge == 1024 and mode_name == "fused") else "0")
+        want_pmc = world == 1 and n_edge == 1024 and mode_name == "fused" and os.environ.get("FDTD_BENCH_PMC", "1") != "0"
+        if world == 1 and (extra_scale in ("full", "small", "1") or want_pmc):
+            eng.close()                   # the children need the memory (fp64 at 1024^3 holds 161 GB)
+        if want_pmc:
+            rec, src = live_traffic(roof["kernel"], has_mu)
+            if rec is not None:
+                t_launch = roof["kernel_ms_per_step"] * 1e-3 * roof["steps_per_launch"]
+                roof.update({"traffic": rec["total_bytes"], "traffic_read_bytes": rec["read_bytes"], "traffic_write_bytes": rec["write_bytes"],
+                             "traffic_source": src, "traffic_rate_GBs": rec["total_bytes"] / t_launch / 1e9,
+                             "traffic_frac_of_peak": rec["total_bytes"] / t_launch / 1e9 / HBM_PEAK_GBS})
+            else:
+                roof["traffic_live_error"] = src
         if world == 1 and extra_scale in ("full", "small", "1"):
-            eng.close()                   # the secondary legs need the memory (fp64 at 1024^3 holds 161 GB)
             out["extra"] = extra_legs_in_children("small" if extra_scale == "small" else "full")
         if world == 1 and os.environ.get("FDTD_BENCH_CPU", "1") != "0":
             out["cpu_baseline"] = cpu_baseline()
