@@ -127,3 +127,66 @@ def test_observed_refusals():
                              meta["steps"], precision=32, mode=MODE_FUSED, z_range=(0, meta["N"][2] // 2))
     with pytest.raises(fdtd_amd.engine.EngineError, match="whole grid"):
         slab.step_observed(0, 2, 0.1, 4)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_window_random_configurations(seed, monkeypatch=None):
+    """Random grids (one to three x tiles), CPML layers per face, mu grid or not, precision, workgroup shape, window
+    length and run lengths: fdtd3d_step_observed with two steps per launch against an engine that steps and
+    accumulates one step at a time -- both windows and all six stored arrays, bit for bit."""
+    import os
+    os.environ["FDTD_PAIR"] = "1"
+    try:
+        rng = np.random.default_rng(5000 + seed)
+        prec = int(rng.choice([32, 64]))
+        tile = 124 if prec == 32 else 60
+        N = (int(rng.choice([rng.integers(5, 40), tile - 1, tile, tile + 1, rng.integers(tile, 3 * tile)])),
+             int(rng.integers(4, 46)), int(rng.integers(4, 40)))
+
+        def layers(n):
+            lo, hi = int(rng.integers(0, 1 + min(12, (n - 2) // 2))), int(rng.integers(0, 1 + min(12, (n - 2) // 2)))
+            return (lo if rng.random() < 0.8 else 0, hi if rng.random() < 0.8 else 0)
+        npml = layers(N[0]) + layers(N[1]) + layers(N[2])
+        if npml[0] and npml[1] and (N[0] - npml[1]) // 4 * 4 < -(-(npml[0] + 1) // 4) * 4:
+            npml = (0,) + npml[1:]
+        has_mu = bool(rng.integers(0, 2))
+        rows, chunk = int(rng.integers(6, 17)), int(rng.choice([1, 2, 3, 5, 8, 48]))
+        window = int(rng.choice([1, 2, 3, 4, 5, 8]))
+        K = po.consts()
+        d = (5e-8, 6e-8, 7e-8)
+        dt = 5e-8 / (2 * K["c0"])
+        counts = [int(rng.integers(1, 8)) for _ in range(3)]
+        steps = sum(counts)
+        kJ = int(rng.integers(0, N[2] + 1))
+        wf, mag = po.default_source3d(N[0], N[1], steps, d, dt)
+        mag = rng.random(mag.shape)
+        engs = [fdtd_amd.Engine3D(N, npml, d, dt, K["mu0"], kJ, steps, precision=prec, mode=MODE_FUSED, has_mu=has_mu) for _ in range(2)]
+        engs[0].pair_shape(chunk, rows)
+        for eng in engs:
+            for a in range(3):
+                for s_ in range(2):
+                    if npml[a * 2 + s_]:
+                        tabs = po.cpml_face(npml[a * 2 + s_], s_, d[a], d[a], dt)
+                        for k in range(6):
+                            eng.set(po.tab_id(a, s_, k), tabs[k])
+            eng.set(po.JX_WF, wf)
+            eng.set(po.JX_MAG, mag)
+            eng.fill_materials(91 + seed, K["eps0"], 4 * K["eps0"], K["mu0"], (2 if has_mu else 1) * K["mu0"])
+        what = f"N={N} npml={npml} mu={has_mu} fp{prec} rows={rows} chunk={chunk} window={window} counts={counts}"
+        n, kept = 0, None
+        for count in counts:
+            engs[0].step_observed(n, count, 0.3, window)
+            for m in range(n, n + count):
+                engs[1].fused(m)
+                engs[1].observe_accumulate(0.3, m % window == 0)
+                if (m + 1) % window == 0:
+                    kept = engs[1].observe_rms().copy()
+            n += count
+            if n % window != 0:
+                util.assert_equal_arrays(engs[0].observe_rms(), engs[1].observe_rms(), f"{what}: accumulating after step {n - 1}")
+            if kept is not None:
+                util.assert_equal_arrays(engs[0].observe_rms_window(), kept, f"{what}: completed window after step {n - 1}")
+        for id_ in [po.DX, po.DY, po.DZ, po.BX, po.BY, po.BZ]:
+            util.assert_equal_arrays(engs[0].get(id_), engs[1].get(id_), f"{what} array {id_}")
+    finally:
+        os.environ.pop("FDTD_PAIR", None)

@@ -1,15 +1,28 @@
-"""The suite's randomized parity tests (fused, two steps per launch and two-kernel, 3-D whole grids and slab partitions, 2-D)
+"""The suite's randomized parity tests (fused, two steps per launch, the RMS window inside them, slab groups in both choreographies, two-kernel, 3-D whole grids and slab partitions, 2-D)
 over a range of further seeds:  python tools/stress_parity.py LO HI   (needs the GPU; ~8 seeds per second)."""
 import sys, time, traceback
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests import test_gpu_fused as tf, test_gpu_fused2d as t2, test_gpu_parity as tp, test_gpu_group as tg, test_gpu_pair as tq
+from tests import test_gpu_fused as tf, test_gpu_fused2d as t2, test_gpu_parity as tp, test_gpu_group as tg, test_gpu_pair as tq, test_gpu_observed as to
+
+
+def group_two_step(seed):
+    """The random slab groups with two steps per launch wherever their cuts allow it."""
+    os.environ["FDTD_PAIR"] = "1"
+    try:
+        tg.test_group_random_configurations_equal_twin(seed, "1")
+    finally:
+        os.environ.pop("FDTD_PAIR", None)
+
+
+
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 t0 = time.time()
 for seed in range(lo, hi):
     for name, fn in (("fused3d", tf.test_fused_random_configurations_equal_twin), ("slabs3d", tf.test_fused_random_slab_partitions_equal_twin),
-                     ("group3d", tg.test_group_random_configurations_equal_twin),
+                     ("group3d", lambda seed: tg.test_group_random_configurations_equal_twin(seed, None)), ("group3d two-step", group_two_step),
+                     ("window3d", to.test_window_random_configurations),
                      ("pairs3d", tq.test_pairs_equal_single_steps_random_configurations)):
         try:
             fn(seed)
