@@ -5,6 +5,8 @@
 // spread over the GPUs of one node, for callers that do not want one process per GPU.
 #include "common.hpp"
 
+#include <dlfcn.h>
+
 #include <cstdlib>
 #include <memory>
 #include <unordered_map>
@@ -38,6 +40,15 @@ struct fdtd3d_group {
     // Slab r-1 waits for sent_down[r], slab r+1 for sent_up[r].
     std::vector<hipEvent_t> edge_done, top_done, sent_down, sent_up;
     bool exchanged_once = false;                // overlapping slabs: the arrival events have been recorded at least once
+    // Transport of the planes: device-to-device copies issued by the sender's copy stream (default), or RCCL
+    // ncclSend / ncclRecv (one communicator per distinct device, created with ncclCommInitAll; slabs that share a device
+    // share its rank and exchange with themselves).  With RCCL the receiving side has streams and arrival events of its
+    // own: rx_lo[r] / got_lo[r] for what comes from the slab below, rx_hi[r] / got_hi[r] for what comes from above.
+    bool rccl = false;
+    std::vector<void*> comm;                    // ncclComm_t per rank
+    std::vector<int> rank_of;                   // slab -> rank
+    std::vector<hipStream_t> rx_lo, rx_hi;
+    std::vector<hipEvent_t> got_lo, got_hi;
     // The slab every stream and event was created for, so that record() can refuse a pair that would
     // sit on different devices on a multi-GPU node -- also when all slabs share one device, where HIP
     // itself would accept it.
@@ -55,11 +66,13 @@ struct fdtd3d_group {
         }
         for (size_t r = 0; r < member.size(); ++r) {
             DeviceScope scope(device[r]);
-            for (auto* v : {&run, &up, &down}) if (r < v->size() && (*v)[r]) (void)hipStreamDestroy((*v)[r]);
-            for (auto* v : {&edge_done, &top_done, &sent_down, &sent_up}) if (r < v->size() && (*v)[r]) (void)hipEventDestroy((*v)[r]);
+            for (auto* v : {&run, &up, &down, &rx_lo, &rx_hi}) if (r < v->size() && (*v)[r]) (void)hipStreamDestroy((*v)[r]);
+            for (auto* v : {&edge_done, &top_done, &sent_down, &sent_up, &got_lo, &got_hi}) if (r < v->size() && (*v)[r]) (void)hipEventDestroy((*v)[r]);
             if (member[r]) fdtd3d_destroy(member[r]);
         }
+        destroy_comms();
     }
+    void destroy_comms();
 };
 
 namespace {
@@ -77,9 +90,50 @@ int record(fdtd3d_group* g, hipEvent_t ev, hipStream_t stream) {
     return FDTD_OK;
 }
 
-// One x-y plane pair (components 0 and 1) from `src`'s send planes into `dst`'s ghost planes, on
-// `stream` (a stream of the source's device, which must be current).
-int copy_planes(fdtd3d_group* g, int src, int which_src, int dst, int which_dst, int parity, hipStream_t stream) {
+// ---- RCCL, bound at run time ------------------------------------------------------------------------------------
+// The library is only looked for when a group asks for this transport, so nothing links against it: a copy the process
+// has loaded already (PyTorch brings one) is used if there is one, else the ROCm installation's.
+struct RcclApi {
+    void* lib = nullptr;
+    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+    int (*CommDestroy)(void* comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void* buf, size_t count, int datatype, int peer, void* comm, hipStream_t stream) = nullptr;
+    int (*Recv)(void* buf, size_t count, int datatype, int peer, void* comm, hipStream_t stream) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclInt8 = 0;            // ncclInt8 / ncclChar (rccl.h): planes travel as bytes
+RcclApi g_rccl;
+int g_default_transport = -1;           // -1: FDTD_GROUP_TRANSPORT in the environment decides; 0 copies, 1 RCCL
+
+int rccl_load() {
+    if (g_rccl.lib) return FDTD_OK;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so"}) if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) if (!h) h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(FDTD_ERR_STATE, "group: RCCL transport asked for, but librccl cannot be loaded (%s)", dlerror());
+    RcclApi a;
+    a.lib = h;
+    bool ok = true;
+    auto sym = [&](auto& fn, const char* name) { fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(h, name)); ok = ok && fn != nullptr; };
+    sym(a.CommInitAll, "ncclCommInitAll"); sym(a.CommDestroy, "ncclCommDestroy"); sym(a.GroupStart, "ncclGroupStart");
+    sym(a.GroupEnd, "ncclGroupEnd"); sym(a.Send, "ncclSend"); sym(a.Recv, "ncclRecv"); sym(a.GetErrorString, "ncclGetErrorString");
+    if (!ok) return fail(FDTD_ERR_STATE, "group: librccl lacks one of ncclCommInitAll / ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
+    g_rccl = a;
+    return FDTD_OK;
+}
+#define FDTD_NCCL(expr)                                                                                       \
+    do {                                                                                                      \
+        const int r_ = (expr);                                                                                \
+        if (r_ != 0) return fail(FDTD_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));           \
+    } while (0)
+
+// ---- moving planes between neighbouring slabs -----------------------------------------------------------------
+struct Piece { const void* from; void* to; size_t nb; };
+
+// The ghost-plane pair (components 0 and 1) of the one-step choreographies.
+int halo_pieces(fdtd3d_group* g, int src, int which_src, int dst, int which_dst, int parity, std::vector<Piece>& out) {
     for (int c = 0; c < 2; ++c) {
         void *from = nullptr, *to = nullptr;
         size_t nb = 0, nb2 = 0;
@@ -88,27 +142,63 @@ int copy_planes(fdtd3d_group* g, int src, int which_src, int dst, int which_dst,
         rc = g->fused ? fdtd3d_halo_at(g->member[dst], parity, which_dst, c, &to, &nb2) : fdtd3d_halo(g->member[dst], which_dst, c, &to, &nb2);
         if (rc) return rc;
         if (nb != nb2) return fail(FDTD_ERR_STATE, "group: ghost planes of slabs %d and %d differ in size", src, dst);
-        if (g->device[src] == g->device[dst]) FDTD_HIP(hipMemcpyAsync(to, from, nb, hipMemcpyDeviceToDevice, stream));
-        else FDTD_HIP(hipMemcpyPeerAsync(to, g->device[dst], from, g->device[src], nb, stream));
+        out.push_back(Piece{from, to, nb});
     }
     return FDTD_OK;
 }
-
-// ---- two steps per launch ------------------------------------------------------------------------------------
-// `count` planes of every exchanged array from global plane k of slab `src` into the same planes of slab `dst`
-// (current buffers of both), on `stream` (a stream of the source's device, which must be current).
-int copy_cut_planes(fdtd3d_group* g, int src, int dst, int k, hipStream_t stream) {
+// Two planes of every exchanged array from global plane k (two steps per launch: the planes beyond a cut), current
+// buffers of both slabs.
+int cut_pieces(fdtd3d_group* g, int src, int dst, int k, std::vector<Piece>& out) {
     for (int id : g->xchg_ids) {
         void *from = nullptr, *to = nullptr;
         size_t nb = 0, nb2 = 0;
         if (int rc = fdtd3d_planes(g->member[src], id, k, 2, &from, &nb)) return rc;
         if (int rc = fdtd3d_planes(g->member[dst], id, k, 2, &to, &nb2)) return rc;
         if (nb != nb2) return fail(FDTD_ERR_STATE, "group: planes of array %d differ in size between slabs %d and %d", id, src, dst);
-        if (g->device[src] == g->device[dst]) FDTD_HIP(hipMemcpyAsync(to, from, nb, hipMemcpyDeviceToDevice, stream));
-        else FDTD_HIP(hipMemcpyPeerAsync(to, g->device[dst], from, g->device[src], nb, stream));
+        out.push_back(Piece{from, to, nb});
     }
     return FDTD_OK;
 }
+// Moves `pieces` from slab src to the slab above (`up`) or below it, once `src_ready` (the planes hold what is to be
+// sent) and `dst_free` (what the destination planes held has been used).  Copies: the sender's copy stream waits for
+// both and copies, over xGMI between different devices.  RCCL: ncclSend on the sender's copy stream after src_ready,
+// ncclRecv on the receiver's stream after dst_free, one group per call.  sent_up / sent_down[src] is recorded on the
+// sender's stream either way; a consumer on the receiving slab waits for arrival().
+int transfer(fdtd3d_group* g, bool up, int src, hipEvent_t src_ready, hipEvent_t dst_free, const std::vector<Piece>& pieces) {
+    const int dst = up ? src + 1 : src - 1;
+    hipStream_t tx = up ? g->up[src] : g->down[src];
+    hipEvent_t sent = up ? g->sent_up[src] : g->sent_down[src];
+    if (!g->rccl) {
+        DeviceScope scope(g->device[src]);
+        FDTD_HIP(hipStreamWaitEvent(tx, src_ready, 0));
+        FDTD_HIP(hipStreamWaitEvent(tx, dst_free, 0));
+        for (const Piece& p : pieces) {
+            if (g->device[src] == g->device[dst]) FDTD_HIP(hipMemcpyAsync(p.to, p.from, p.nb, hipMemcpyDeviceToDevice, tx));
+            else FDTD_HIP(hipMemcpyPeerAsync(p.to, g->device[dst], p.from, g->device[src], p.nb, tx));
+        }
+        return record(g, sent, tx);
+    }
+    hipStream_t rx = up ? g->rx_lo[dst] : g->rx_hi[dst];
+    hipEvent_t got = up ? g->got_lo[dst] : g->got_hi[dst];
+    { DeviceScope scope(g->device[src]); FDTD_HIP(hipStreamWaitEvent(tx, src_ready, 0)); }
+    { DeviceScope scope(g->device[dst]); FDTD_HIP(hipStreamWaitEvent(rx, dst_free, 0)); }
+    FDTD_NCCL(g_rccl.GroupStart());
+    for (const Piece& p : pieces) {
+        { DeviceScope scope(g->device[src]); FDTD_NCCL(g_rccl.Send(p.from, p.nb, kNcclInt8, g->rank_of[dst], g->comm[g->rank_of[src]], tx)); }
+        { DeviceScope scope(g->device[dst]); FDTD_NCCL(g_rccl.Recv(p.to, p.nb, kNcclInt8, g->rank_of[src], g->comm[g->rank_of[dst]], rx)); }
+    }
+    FDTD_NCCL(g_rccl.GroupEnd());
+    { DeviceScope scope(g->device[src]); if (int rc = record(g, sent, tx)) return rc; }
+    { DeviceScope scope(g->device[dst]); if (int rc = record(g, got, rx)) return rc; }
+    return FDTD_OK;
+}
+// The event after which the planes that slab `src` sent up (down) are in its neighbour's memory.
+hipEvent_t arrival(fdtd3d_group* g, bool up, int src) {
+    if (!g->rccl) return up ? g->sent_up[src] : g->sent_down[src];
+    return up ? g->got_lo[src + 1] : g->got_hi[src - 1];
+}
+
+// ---- two steps per launch ------------------------------------------------------------------------------------
 // After the launches that produced the planes next to the cuts (recorded as edge_done): the two planes below every cut
 // go up, the two above it go down.  The copies run on the copy streams, beside whatever the launch streams do next
 // (the bulk of a two-step launch neither reads the buffers the planes land in nor writes those planes).
@@ -117,20 +207,11 @@ int exchange_cut_planes(fdtd3d_group* g) {
     int rc;
     for (int r = 0; r + 1 < R; ++r) {
         const int cut = g->hi[r];
-        {
-            DeviceScope scope(g->device[r]);
-            FDTD_HIP(hipStreamWaitEvent(g->up[r], g->edge_done[r], 0));
-            FDTD_HIP(hipStreamWaitEvent(g->up[r], g->edge_done[r + 1], 0));
-            if ((rc = copy_cut_planes(g, r, r + 1, cut - 2, g->up[r]))) return rc;
-            if ((rc = record(g, g->sent_up[r], g->up[r]))) return rc;
-        }
-        {
-            DeviceScope scope(g->device[r + 1]);
-            FDTD_HIP(hipStreamWaitEvent(g->down[r + 1], g->edge_done[r + 1], 0));
-            FDTD_HIP(hipStreamWaitEvent(g->down[r + 1], g->edge_done[r], 0));
-            if ((rc = copy_cut_planes(g, r + 1, r, cut, g->down[r + 1]))) return rc;
-            if ((rc = record(g, g->sent_down[r + 1], g->down[r + 1]))) return rc;
-        }
+        std::vector<Piece> going_up, going_down;
+        if ((rc = cut_pieces(g, r, r + 1, cut - 2, going_up))) return rc;
+        if ((rc = cut_pieces(g, r + 1, r, cut, going_down))) return rc;
+        if ((rc = transfer(g, true, r, g->edge_done[r], g->edge_done[r + 1], going_up))) return rc;
+        if ((rc = transfer(g, false, r + 1, g->edge_done[r + 1], g->edge_done[r], going_down))) return rc;
     }
     return FDTD_OK;
 }
@@ -138,8 +219,8 @@ int exchange_cut_planes(fdtd3d_group* g) {
 int wait_for_cut_planes(fdtd3d_group* g, int r) {
     const int R = (int)g->member.size();
     if (!g->exchanged_once) return FDTD_OK;
-    if (r > 0) { FDTD_HIP(hipStreamWaitEvent(g->run[r], g->sent_up[r - 1], 0)); FDTD_HIP(hipStreamWaitEvent(g->run[r], g->sent_down[r], 0)); }
-    if (r + 1 < R) { FDTD_HIP(hipStreamWaitEvent(g->run[r], g->sent_down[r + 1], 0)); FDTD_HIP(hipStreamWaitEvent(g->run[r], g->sent_up[r], 0)); }
+    if (r > 0) { FDTD_HIP(hipStreamWaitEvent(g->run[r], arrival(g, true, r - 1), 0)); FDTD_HIP(hipStreamWaitEvent(g->run[r], g->sent_down[r], 0)); }
+    if (r + 1 < R) { FDTD_HIP(hipStreamWaitEvent(g->run[r], arrival(g, false, r + 1), 0)); FDTD_HIP(hipStreamWaitEvent(g->run[r], g->sent_up[r], 0)); }
     return FDTD_OK;
 }
 // Steps n and n+1 in one launch per slab, cut in two (fdtd3d_pair_part): the three planes at either end first, the
@@ -188,31 +269,27 @@ int step_fused(fdtd3d_group* g, int n) {
     int rc;
     for (int r = 0; r < R; ++r) {
         DeviceScope scope(g->device[r]);
-        if (r > 0) FDTD_HIP(hipStreamWaitEvent(g->run[r], g->sent_up[r - 1], 0));
+        if (r > 0) FDTD_HIP(hipStreamWaitEvent(g->run[r], arrival(g, true, r - 1), 0));
         if ((rc = fdtd3d_fused(g->member[r], n, FDTD3D_PART_EDGE, g->run[r]))) return rc;
         if ((rc = record(g, g->edge_done[r], g->run[r]))) return rc;
     }
     const int parity = fdtd3d_buffer_parity(g->member[0]);       // all members change buffers together
     for (int r = 1; r < R; ++r) {
-        DeviceScope scope(g->device[r]);
-        FDTD_HIP(hipStreamWaitEvent(g->down[r], g->edge_done[r], 0));
-        FDTD_HIP(hipStreamWaitEvent(g->down[r], g->top_done[r - 1], 0));     // the ghost's previous content has been used
-        if ((rc = copy_planes(g, r, FDTD3D_HALO_SEND_DOWN, r - 1, FDTD3D_HALO_RECV_HI, parity, g->down[r]))) return rc;
-        if ((rc = record(g, g->sent_down[r], g->down[r]))) return rc;
+        std::vector<Piece> pieces;
+        if ((rc = halo_pieces(g, r, FDTD3D_HALO_SEND_DOWN, r - 1, FDTD3D_HALO_RECV_HI, parity, pieces))) return rc;
+        if ((rc = transfer(g, false, r, g->edge_done[r], g->top_done[r - 1], pieces))) return rc;      // (top_done: the ghost's previous content has been used)
     }
     for (int r = 0; r < R; ++r) {
         DeviceScope scope(g->device[r]);
         if ((rc = fdtd3d_fused(g->member[r], n, FDTD3D_PART_TOP, g->run[r]))) return rc;
-        if (r + 1 < R) FDTD_HIP(hipStreamWaitEvent(g->run[r], g->sent_down[r + 1], 0));
+        if (r + 1 < R) FDTD_HIP(hipStreamWaitEvent(g->run[r], arrival(g, false, r + 1), 0));
         if ((rc = fdtd3d_fused_top(g->member[r], g->run[r]))) return rc;
         if ((rc = record(g, g->top_done[r], g->run[r]))) return rc;
     }
     for (int r = 0; r + 1 < R; ++r) {
-        DeviceScope scope(g->device[r]);
-        FDTD_HIP(hipStreamWaitEvent(g->up[r], g->top_done[r], 0));
-        FDTD_HIP(hipStreamWaitEvent(g->up[r], g->edge_done[r + 1], 0));      // the ghost's previous content has been used
-        if ((rc = copy_planes(g, r, FDTD3D_HALO_SEND_UP, r + 1, FDTD3D_HALO_RECV_LO, parity, g->up[r]))) return rc;
-        if ((rc = record(g, g->sent_up[r], g->up[r]))) return rc;
+        std::vector<Piece> pieces;
+        if ((rc = halo_pieces(g, r, FDTD3D_HALO_SEND_UP, r + 1, FDTD3D_HALO_RECV_LO, parity, pieces))) return rc;
+        if ((rc = transfer(g, true, r, g->top_done[r], g->edge_done[r + 1], pieces))) return rc;        // (edge_done: the ghost's previous content has been used)
     }
     for (int r = 0; r < R; ++r) {
         DeviceScope scope(g->device[r]);
@@ -230,30 +307,26 @@ int step_halves(fdtd3d_group* g, int n) {
     for (int r = 0; r < R; ++r) {
         DeviceScope scope(g->device[r]);
         if ((rc = fdtd3d_half_e(g->member[r], n, FDTD3D_PART_INTERIOR, g->run[r]))) return rc;
-        if (r > 0) FDTD_HIP(hipStreamWaitEvent(g->run[r], g->sent_up[r - 1], 0));
+        if (r > 0) FDTD_HIP(hipStreamWaitEvent(g->run[r], arrival(g, true, r - 1), 0));
         if ((rc = fdtd3d_half_e(g->member[r], n, FDTD3D_PART_EDGE, g->run[r]))) return rc;
         if ((rc = record(g, g->edge_done[r], g->run[r]))) return rc;
     }
     for (int r = 1; r < R; ++r) {
-        DeviceScope scope(g->device[r]);
-        FDTD_HIP(hipStreamWaitEvent(g->down[r], g->edge_done[r], 0));
-        FDTD_HIP(hipStreamWaitEvent(g->down[r], g->top_done[r - 1], 0));
-        if ((rc = copy_planes(g, r, FDTD3D_HALO_SEND_DOWN, r - 1, FDTD3D_HALO_RECV_HI, 0, g->down[r]))) return rc;
-        if ((rc = record(g, g->sent_down[r], g->down[r]))) return rc;
+        std::vector<Piece> pieces;
+        if ((rc = halo_pieces(g, r, FDTD3D_HALO_SEND_DOWN, r - 1, FDTD3D_HALO_RECV_HI, 0, pieces))) return rc;
+        if ((rc = transfer(g, false, r, g->edge_done[r], g->top_done[r - 1], pieces))) return rc;
     }
     for (int r = 0; r < R; ++r) {
         DeviceScope scope(g->device[r]);
         if ((rc = fdtd3d_half_h(g->member[r], FDTD3D_PART_INTERIOR, g->run[r]))) return rc;
-        if (r + 1 < R) FDTD_HIP(hipStreamWaitEvent(g->run[r], g->sent_down[r + 1], 0));
+        if (r + 1 < R) FDTD_HIP(hipStreamWaitEvent(g->run[r], arrival(g, false, r + 1), 0));
         if ((rc = fdtd3d_half_h(g->member[r], FDTD3D_PART_EDGE, g->run[r]))) return rc;
         if ((rc = record(g, g->top_done[r], g->run[r]))) return rc;
     }
     for (int r = 0; r + 1 < R; ++r) {
-        DeviceScope scope(g->device[r]);
-        FDTD_HIP(hipStreamWaitEvent(g->up[r], g->top_done[r], 0));
-        FDTD_HIP(hipStreamWaitEvent(g->up[r], g->edge_done[r + 1], 0));
-        if ((rc = copy_planes(g, r, FDTD3D_HALO_SEND_UP, r + 1, FDTD3D_HALO_RECV_LO, 0, g->up[r]))) return rc;
-        if ((rc = record(g, g->sent_up[r], g->up[r]))) return rc;
+        std::vector<Piece> pieces;
+        if ((rc = halo_pieces(g, r, FDTD3D_HALO_SEND_UP, r + 1, FDTD3D_HALO_RECV_LO, 0, pieces))) return rc;
+        if ((rc = transfer(g, true, r, g->top_done[r], g->edge_done[r + 1], pieces))) return rc;
     }
     for (int r = 0; r < R; ++r) {
         DeviceScope scope(g->device[r]);
@@ -330,6 +403,23 @@ int build_group(fdtd3d_group* g, const fdtd3d_desc* desc, int n_slabs, const int
             if (nb >= 0 && nb < n_slabs && g->device[nb] != g->device[r])
                 if (int rc = fdtd3d_grant_peer_access(g->member[r], g->device[nb])) return rc;
     const size_t R = (size_t)n_slabs;
+    // transport of the planes: FDTD_GROUP_TRANSPORT=rccl in the environment, or fdtd3d_group_default_transport(1)
+    int transport = g_default_transport;
+    if (transport < 0) { const char* e = getenv("FDTD_GROUP_TRANSPORT"); transport = (e && std::string(e) == "rccl") ? 1 : 0; }
+    if (transport == 1 && n_slabs > 1) {
+        if (int rc = rccl_load()) return rc;
+        std::vector<int> devs;
+        for (int r = 0; r < n_slabs; ++r) {
+            size_t q = 0;
+            while (q < devs.size() && devs[q] != g->device[r]) ++q;
+            if (q == devs.size()) devs.push_back(g->device[r]);
+            g->rank_of.push_back((int)q);
+        }
+        g->comm.assign(devs.size(), nullptr);
+        FDTD_NCCL(g_rccl.CommInitAll(g->comm.data(), (int)devs.size(), devs.data()));
+        g->rccl = true;
+        g->rx_lo.assign(R, nullptr); g->rx_hi.assign(R, nullptr); g->got_lo.assign(R, nullptr); g->got_hi.assign(R, nullptr);
+    }
     g->run.assign(R, nullptr); g->up.assign(R, nullptr); g->down.assign(R, nullptr);
     g->edge_done.assign(R, nullptr); g->top_done.assign(R, nullptr); g->sent_down.assign(R, nullptr); g->sent_up.assign(R, nullptr);
     // (tests only, fdtd3d_group_debug_misown_events) the two arrival events filed under the RECEIVING slab, the
@@ -348,6 +438,10 @@ int build_group(fdtd3d_group* g, const fdtd3d_desc* desc, int n_slabs, const int
             if (misown && v == &g->sent_up && r + 1 < R) own = (int)r + 1;
             g->owner[(void*)(*v)[r]] = own;
         }
+        if (g->rccl) {
+            for (auto* v : {&g->rx_lo, &g->rx_hi}) { FDTD_HIP(hipStreamCreate(&(*v)[r])); g->owner[(void*)(*v)[r]] = (int)r; }
+            for (auto* v : {&g->got_lo, &g->got_hi}) { FDTD_HIP(hipEventCreateWithFlags(&(*v)[r], hipEventDisableTiming)); g->owner[(void*)(*v)[r]] = (int)r; }
+        }
     }
     return FDTD_OK;
 }
@@ -362,7 +456,15 @@ int each_member(fdtd3d_group_handle g, F&& f) {
 
 }  // namespace
 
+void fdtd3d_group::destroy_comms() {
+    for (void* c : comm) if (c && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c);
+    comm.clear();
+}
+
 extern "C" {
+
+void fdtd3d_group_default_transport(int transport) { g_default_transport = (transport == 0 || transport == 1) ? transport : -1; }
+int fdtd3d_group_transport(fdtd3d_group_handle g) { return (g && g->rccl) ? 1 : 0; }
 
 int fdtd3d_group_create(const fdtd3d_desc* desc, int n_slabs, const int* devices, fdtd3d_group_handle* out) {
     if (!out) return fail(FDTD_ERR_ARG, "null output handle");
@@ -435,6 +537,7 @@ int fdtd3d_group_sync(fdtd3d_group_handle g) {
         FDTD_HIP(hipStreamSynchronize(g->run[r]));
         FDTD_HIP(hipStreamSynchronize(g->up[r]));
         FDTD_HIP(hipStreamSynchronize(g->down[r]));
+        if (g->rccl) { FDTD_HIP(hipStreamSynchronize(g->rx_lo[r])); FDTD_HIP(hipStreamSynchronize(g->rx_hi[r])); }
     }
     return FDTD_OK;
 }

@@ -360,6 +360,16 @@ int fdtd3d_group_slabs(fdtd3d_group_handle g);
  * every single step), the one-step choreography runs.  fdtd3d_group_pairs() tells (1/0); fdtd3d_group_bounds() gives
  * the layers [lo, hi) slab r answers for (what its handle stores may be one layer more either side). */
 int fdtd3d_group_pairs(fdtd3d_group_handle g);
+/* How the planes travel between the slabs of groups created from now on: 0 = device-to-device copies issued by the
+ * sender's copy stream (hipMemcpyPeerAsync between different devices; the default), 1 = RCCL: one communicator per
+ * distinct device (ncclCommInitAll), ncclSend on the sender's copy stream and ncclRecv on a stream of the receiving
+ * slab's device, one ncclGroupStart/End per neighbour exchange; slabs that share a device share its rank and exchange
+ * with themselves.  -1 = let FDTD_GROUP_TRANSPORT in the environment decide ("rccl"; anything else: copies).  The RCCL
+ * library is looked for at run time, only when asked for (a copy the process has already loaded, else the ROCm
+ * installation's); group creation fails with FDTD_ERR_STATE if it cannot be found.  Same results either way.
+ * fdtd3d_group_transport() tells what a group uses. */
+void fdtd3d_group_default_transport(int transport);
+int fdtd3d_group_transport(fdtd3d_group_handle g);
 int fdtd3d_group_bounds(fdtd3d_group_handle g, int r, int* lo, int* hi);
 /* Every event of a group is recorded through a check that event and stream were created for the same
  * slab (HIP refuses to record an event on a stream of another device; with all slabs on one device

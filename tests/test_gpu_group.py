@@ -235,3 +235,33 @@ def test_group_two_step_launches_with_observed_steps_and_resume(monkeypatch):
         if g2.size(id_):
             util.assert_equal_arrays(g2.get(id_), tw.get(id_), f"array {id_} after the resumed run")
     g2.close()
+
+
+@pytest.mark.parametrize("mode,pairs", [(E.MODE_FUSED, None), (E.MODE_FUSED, "1"), (E.MODE_LEAN, None), (E.MODE_FULL, None)])
+def test_group_planes_travel_by_rccl(mode, pairs, monkeypatch):
+    """The same choreographies with ncclSend / ncclRecv in place of the device-to-device copies.  On a one-GPU box every
+    slab has the rank of device 0, so each exchange is a rank sending to itself and receiving from itself -- the RCCL
+    calls, their grouping, the receiving side's streams and arrival events are the ones a multi-GPU node runs."""
+    if pairs:
+        monkeypatch.setenv("FDTD_PAIR", pairs)
+    meta, ins, _, _ = util.load_fixture("g1_3d_cpml")
+    L = E.lib()
+    L.fdtd3d_group_default_transport(1)
+    try:
+        g = group_from_meta(meta, 32, 3, mode)
+    finally:
+        L.fdtd3d_group_default_transport(-1)
+    assert L.fdtd3d_group_transport(g.h) == 1 and g.pairs == bool(pairs)
+    tw = util.twin3d_from_meta(meta, 32)
+    util.feed(g, ins)
+    util.feed(tw, ins)
+    g.step(0, 9)
+    g.step(9, 4)
+    tw.step(0, 13)
+    for id_ in po.FIELDS3D + po.ALL_PHI3D:
+        if g.size(id_):
+            util.assert_equal_arrays(g.get(id_), tw.get(id_), f"RCCL transport, mode {mode}, pairs {pairs}: array {id_}")
+    g.close()
+    plain = group_from_meta(meta, 32, 2, mode)
+    assert L.fdtd3d_group_transport(plain.h) == 0
+    plain.close()
