@@ -191,11 +191,12 @@ __global__ void k_reduce_finish(const double* slots, double* results, int n_ids)
 // array by itself when asked to); MODE 1: out0 = (1/4) sx (centred Ex), out1 = ax^2 + ay^2 + az^2 (|E|^2),
 // x fastest, then y, then z -- the order the reference hands to its VTI writer.
 template <typename T, bool LEAN, int MODE>
-__global__ void k3_observe(const K3<T> a, T* out0, T* out1, T weight, int reset, int nzl) {
+__global__ void k3_observe(const K3<T> a, T* out0, T* out1, T weight, int reset, int kl_first, int nzl) {
+    // the cell layers between the local planes kl_first .. kl_first + nzl
     const size_t cells = (size_t)a.Nx * a.Ny * nzl;
     const size_t sz = (size_t)a.ny1 * a.px;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < cells; t += (size_t)gridDim.x * blockDim.x) {
-        const int i = (int)(t % a.Nx), j = (int)((t / a.Nx) % a.Ny), kl = 1 + (int)(t / ((size_t)a.Nx * a.Ny));
+        const int i = (int)(t % a.Nx), j = (int)((t / a.Nx) % a.Ny), kl = kl_first + (int)(t / ((size_t)a.Nx * a.Ny));
         const size_t id = ((size_t)kl * a.ny1 + j) * a.px + i;
         const bool wall = i + 1 >= a.Nx;          // column Nx of Ey, Ez is the unstored zero wall
         const T sx = load_e1<T, LEAN>(a, 0, id) + load_e1<T, LEAN>(a, 0, id + a.px) + load_e1<T, LEAN>(a, 0, id + sz) + load_e1<T, LEAN>(a, 0, id + sz + a.px);
@@ -215,10 +216,10 @@ __global__ void k3_observe(const K3<T> a, T* out0, T* out1, T weight, int reset,
 
 // The window array without its padding: [owned layers][Ny][Nx], x fastest.
 template <typename T>
-__global__ void k3_unpad(const T* __restrict__ padded, T* __restrict__ dense, int Nx, int Ny, int nzl, int px, int ny1) {
+__global__ void k3_unpad(const T* __restrict__ padded, T* __restrict__ dense, int Nx, int Ny, int kl_first, int nzl, int px, int ny1) {
     const size_t cells = (size_t)Nx * Ny * nzl;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < cells; t += (size_t)gridDim.x * blockDim.x) {
-        const int i = (int)(t % Nx), j = (int)((t / Nx) % Ny), kl = 1 + (int)(t / ((size_t)Nx * Ny));
+        const int i = (int)(t % Nx), j = (int)((t / Nx) % Ny), kl = kl_first + (int)(t / ((size_t)Nx * Ny));
         dense[t] = padded[((size_t)kl * ny1 + j) * px + i];
     }
 }
@@ -304,6 +305,9 @@ struct fdtd3d_engine {
     virtual int observe_keep_window() = 0;
     virtual int observe_rms_window(double* host, size_t n) = 0;
     virtual int step_observed(int n0, int count, double weight, int window, hipStream_t s) = 0;
+    virtual int observe_set_range(int k_lo, int k_hi) = 0;
+    virtual int pair_part_observed(int n, int part, double weight, int window, int defer_top, hipStream_t s) = 0;
+    virtual int observe_finish_pair(int n, double weight, int window, int defer_top, hipStream_t s) = 0;
     virtual int observe_frame(double* ex_center, double* e_mag, size_t n, hipStream_t s) = 0;
     fdtd3d_desc d;
     KernelTimer timer;
@@ -1033,7 +1037,18 @@ struct Engine3 : fdtd3d_engine {
     }
 
     // ---- observables ---------------------------------------------------------------------
-    size_t obs_cells() const { return (size_t)d.Nx * d.Ny * nzl; }
+    // the layers whose observables this engine reports (a slab that overlaps its neighbours stores more than it answers for)
+    int ans_lo = -1, ans_hi = -1;
+    int obs_lo() const { return ans_lo >= 0 ? ans_lo : d.z_lo; }
+    int obs_hi() const { return ans_lo >= 0 ? ans_hi : d.z_hi; }
+    int obs_kl() const { return 1 + obs_lo() - d.z_lo; }                 // local plane of the first reported layer
+    size_t obs_cells() const { return (size_t)d.Nx * d.Ny * (obs_hi() - obs_lo()); }
+    int observe_set_range(int k_lo, int k_hi) override {
+        if (k_lo < d.z_lo || k_hi > d.z_hi || k_lo >= k_hi) return fail(FDTD_ERR_ARG, "observe_set_range: [%d,%d) is not inside the stored layers [%d,%d)", k_lo, k_hi, d.z_lo, d.z_hi);
+        if (obs_tmp) return fail(FDTD_ERR_STATE, "observe_set_range: set the range before the first download");
+        ans_lo = k_lo; ans_hi = k_hi;
+        return FDTD_OK;
+    }
     int obs_reserve(bool snap) {
         int rc;
         if (!obs_acc && (rc = dalloc((void**)&obs_acc, (fsize + px) * sizeof(T)))) return rc;
@@ -1042,9 +1057,13 @@ struct Engine3 : fdtd3d_engine {
     }
     int observe_accumulate(double weight, int reset, hipStream_t s) override {
         if (int rc = obs_reserve(false)) return rc;
+        return accumulate_layers(weight, reset, 1, nzl, s);
+    }
+    // the window of the cell layers between the local planes kl_first .. kl_first + count advanced by one step
+    int accumulate_layers(double weight, int reset, int kl_first, int count, hipStream_t s) {
         K3<T> a = args();
-        if (full) hipLaunchKernelGGL((k3_observe<T, false, 0>), dim3(4096), dim3(256), 0, s, a, obs_acc, (T*)nullptr, (T)weight, reset, nzl);
-        else hipLaunchKernelGGL((k3_observe<T, true, 0>), dim3(4096), dim3(256), 0, s, a, obs_acc, (T*)nullptr, (T)weight, reset, nzl);
+        if (full) hipLaunchKernelGGL((k3_observe<T, false, 0>), dim3(4096), dim3(256), 0, s, a, obs_acc, (T*)nullptr, (T)weight, reset, kl_first, count);
+        else hipLaunchKernelGGL((k3_observe<T, true, 0>), dim3(4096), dim3(256), 0, s, a, obs_acc, (T*)nullptr, (T)weight, reset, kl_first, count);
         FDTD_HIP(hipGetLastError());
         return FDTD_OK;
     }
@@ -1062,7 +1081,7 @@ struct Engine3 : fdtd3d_engine {
         std::vector<T> st(obs_cells());
         FDTD_HIP(hipDeviceSynchronize());
         FDTD_HIP(hipMemcpy(st.data(), dev, st.size() * sizeof(T), hipMemcpyDeviceToHost));
-        double* dst = host + (size_t)d.z_lo * d.Ny * d.Nx;
+        double* dst = host + (size_t)obs_lo() * d.Ny * d.Nx;
         for (size_t q = 0; q < st.size(); ++q) dst[q] = take_sqrt ? std::sqrt((double)st[q]) : (double)st[q];
         return FDTD_OK;
     }
@@ -1070,7 +1089,7 @@ struct Engine3 : fdtd3d_engine {
         int rc;
         if (!obs_tmp && (rc = dalloc((void**)&obs_tmp, 2 * obs_cells() * sizeof(T)))) return rc;
         FDTD_HIP(hipDeviceSynchronize());
-        hipLaunchKernelGGL(k3_unpad<T>, dim3(4096), dim3(256), 0, 0, padded, obs_tmp, d.Nx, d.Ny, nzl, px, ny1);
+        hipLaunchKernelGGL(k3_unpad<T>, dim3(4096), dim3(256), 0, 0, padded, obs_tmp, d.Nx, d.Ny, obs_kl(), obs_hi() - obs_lo(), px, ny1);
         FDTD_HIP(hipGetLastError());
         return obs_download(obs_tmp, host, true);
     }
@@ -1083,6 +1102,32 @@ struct Engine3 : fdtd3d_engine {
         if (n != (size_t)d.Nx * d.Ny * d.Nz || !host) return fail(FDTD_ERR_ARG, "observe_rms_window: expected %zu values", (size_t)d.Nx * d.Ny * d.Nz);
         if (!obs_have_window) return fail(FDTD_ERR_STATE, "observe_rms_window: no window has been completed yet");
         return obs_download_window(obs_snap, host);
+    }
+    // Steps n, n+1 of a SLAB in one launch (or its EDGE / INTERIOR part) with the window advanced by both, for drivers of
+    // overlapping slabs (fdtd3d_pair_part).  `defer_top`: the slab has a neighbour above; the second step's contribution
+    // of its top reported layer needs E one layer further up, which is exact only once the planes beyond the cut have
+    // arrived, so the launch leaves it out and observe_finish_pair adds it.
+    int pair_part_observed(int n, int part, double weight, int window, int defer_top, hipStream_t s) override {
+        if (window < 1 || n < 0) return fail(FDTD_ERR_ARG, "pair_part_observed: bad window or step number");
+        if (!probes.specs.empty()) return fail(FDTD_ERR_STATE, "two-step launches cannot sample probes after the first of their steps");
+        if (int rc = obs_reserve(true)) return rc;
+        const bool done1 = (n + 1) % window == 0;
+        pair_acc_w = (T)weight;
+        pair_acc_flags = (n % window == 0 ? 1 : 0) | (done1 ? 2 | 4 : 0);
+        pair_acc_defer = defer_top ? obs_hi() - d.z_lo : -1;           // local plane of the top reported layer (plane = layer - z_lo + 1)
+        const int rc = step_pair_part(n, part, s);
+        pair_acc_flags = -1; pair_acc_defer = -1;
+        if (rc) return rc;
+        if (done1 && part != FDTD3D_PART_EDGE) obs_have_window = true;
+        return FDTD_OK;
+    }
+    // After the planes beyond the cuts have arrived: the deferred contribution, and the change of roles of the two window
+    // arrays if the launch's second step completed a window.
+    int observe_finish_pair(int n, double weight, int window, int defer_top, hipStream_t s) override {
+        if (window < 1 || n < 0) return fail(FDTD_ERR_ARG, "observe_finish_pair: bad window or step number");
+        if (defer_top) if (int rc = accumulate_layers(weight, (n + 1) % window == 0, obs_hi() - d.z_lo, 1, s)) return rc;
+        if ((n + 2) % window == 0) return observe_keep_window();
+        return FDTD_OK;
     }
     // `count` steps from n0, each followed by the accumulation of FDTD3D::run (FDTD3D.cpp:1089-1097): a new window opens
     // at every step n with n % window == 0, and the window that step n completes ((n + 1) % window == 0) is kept for
@@ -1125,8 +1170,8 @@ struct Engine3 : fdtd3d_engine {
         int rc;
         if (!obs_tmp && (rc = dalloc((void**)&obs_tmp, 2 * obs_cells() * sizeof(T)))) return rc;
         K3<T> a = args();
-        if (full) hipLaunchKernelGGL((k3_observe<T, false, 1>), dim3(4096), dim3(256), 0, s, a, obs_tmp, obs_tmp + obs_cells(), (T)0, 0, nzl);
-        else hipLaunchKernelGGL((k3_observe<T, true, 1>), dim3(4096), dim3(256), 0, s, a, obs_tmp, obs_tmp + obs_cells(), (T)0, 0, nzl);
+        if (full) hipLaunchKernelGGL((k3_observe<T, false, 1>), dim3(4096), dim3(256), 0, s, a, obs_tmp, obs_tmp + obs_cells(), (T)0, 0, obs_kl(), obs_hi() - obs_lo());
+        else hipLaunchKernelGGL((k3_observe<T, true, 1>), dim3(4096), dim3(256), 0, s, a, obs_tmp, obs_tmp + obs_cells(), (T)0, 0, obs_kl(), obs_hi() - obs_lo());
         FDTD_HIP(hipGetLastError());
         if ((rc = obs_download(obs_tmp, ex_center, false))) return rc;
         return obs_download(obs_tmp + obs_cells(), e_mag, true);
@@ -1145,7 +1190,7 @@ struct Engine3 : fdtd3d_engine {
         for (int ax = 0; ax < 3; ++ax) for (int s = 0; s < 2; ++s) a.np[ax][s] = np[ax][s];
         a.xwn = xwn; a.xwp = xwp; a.xp0 = xp0;
         a.wrap_l = 0; a.wrap_r0 = 0; a.peek = 0;
-        a.acc = nullptr; a.acc_snap = nullptr; a.acc_w = (T)0; a.acc_flags = 0;
+        a.acc = nullptr; a.acc_snap = nullptr; a.acc_w = (T)0; a.acc_flags = 0; a.acc_defer_kl = -1;
         a.kJ = d.k_Jx; a.src_on = 0; a.jx = (T)0;
         a.dt = (T)d.dt; a.dtd[0] = (T)(d.dt / d.dx); a.dtd[1] = (T)(d.dt / d.dy); a.dtd[2] = (T)(d.dt / d.dz); a.mu0 = (T)d.mu0;
         a.nbx = px / (kLanes * V); a.nby = (ny1 + wpb - 1) / wpb; a.wpb = wpb;
@@ -1480,6 +1525,7 @@ struct Engine3 : fdtd3d_engine {
     hipStream_t pair_stream = nullptr;
     T pair_acc_w = (T)0;              // step_observed: weight and flags of the window the next two-step launch advances
     int pair_acc_flags = -1;          // (-1: the launch leaves the window alone)
+    int pair_acc_defer = -1;
     static constexpr int kPairEdge = 3;
     int step_pair_part(int n, int part, hipStream_t s) override {
         if (!fused) return fail(FDTD_ERR_STATE, "two-step launches need an engine created with FDTD3D_MODE_FUSED");
@@ -1498,11 +1544,9 @@ struct Engine3 : fdtd3d_engine {
         a.src_on = (s1 ? 1 : 0) | (s2 ? 2 : 0);
         a.jx = s1 ? a.dt * wf[n] : (T)0;
         a.jx2 = s2 ? a.dt * wf[n + 1] : (T)0;
-        a.acc = nullptr; a.acc_snap = nullptr; a.acc_w = (T)0; a.acc_flags = 0;
-        if (pair_acc_flags >= 0) {
-            if (part != FDTD3D_PART_ALL) return fail(FDTD_ERR_STATE, "two-step launches advance the RMS window only as a whole launch");
-            a.acc = obs_acc; a.acc_snap = obs_snap; a.acc_w = pair_acc_w; a.acc_flags = pair_acc_flags;
-        }
+        a.acc = nullptr; a.acc_snap = nullptr; a.acc_w = (T)0; a.acc_flags = 0; a.acc_defer_kl = -1;
+        a.acc_defer_kl = -1;
+        if (pair_acc_flags >= 0) { a.acc = obs_acc; a.acc_snap = obs_snap; a.acc_w = pair_acc_w; a.acc_flags = pair_acc_flags; a.acc_defer_kl = pair_acc_defer; }
         if (pml && !phM2_ready) {
             for (int c = 0; c < 3; ++c) for (int ax = 0; ax < 3; ++ax) for (int sd = 0; sd < 2; ++sd)
                 if (phM[c][ax][sd])
@@ -1730,6 +1774,13 @@ int fdtd3d_launch_shape(fdtd3d_handle h, int out[6]) {
 int fdtd3d_tune(fdtd3d_handle h, int chunk, int remap, int rows) { return entry(h, [&] { return h->tune(chunk, remap, rows); }); }
 int fdtd3d_observe_accumulate(fdtd3d_handle h, double weight, int reset, void* stream) { return entry(h, [&] { return h->observe_accumulate(weight, reset, (hipStream_t)stream); }); }
 int fdtd3d_observe_rms(fdtd3d_handle h, double* host, size_t n) { return entry(h, [&] { return h->observe_rms(host, n); }); }
+int fdtd3d_observe_set_range(fdtd3d_handle h, int k_lo, int k_hi) { return entry(h, [&] { return h->observe_set_range(k_lo, k_hi); }); }
+int fdtd3d_pair_part_observed(fdtd3d_handle h, int n, int part, double weight, int window, int defer_top, void* stream) {
+    return entry(h, [&] { return h->pair_part_observed(n, part, weight, window, defer_top, (hipStream_t)stream); });
+}
+int fdtd3d_observe_finish_pair(fdtd3d_handle h, int n, double weight, int window, int defer_top, void* stream) {
+    return entry(h, [&] { return h->observe_finish_pair(n, weight, window, defer_top, (hipStream_t)stream); });
+}
 int fdtd3d_observe_keep_window(fdtd3d_handle h) { return entry(h, [&] { return h->observe_keep_window(); }); }
 int fdtd3d_observe_rms_window(fdtd3d_handle h, double* host, size_t n) { return entry(h, [&] { return h->observe_rms_window(host, n); }); }
 int fdtd3d_step_observed(fdtd3d_handle h, int n0, int count, double weight, int window, void* stream) {

@@ -242,6 +242,32 @@ int step_pair(fdtd3d_group* g, int n) {
     }
     return FDTD_OK;
 }
+// The same with the RMS window of FDTD3D::run advanced inside the launches (fdtd3d_pair_part_observed).  A slab below
+// another one leaves the second step's contribution of its top layer out -- it needs E one layer further up, which is
+// exact only once the planes from above have arrived -- and adds it afterwards with a one-layer launch of the observe
+// kernel, queued behind the bulk on its launch stream.
+int step_pair_observed(fdtd3d_group* g, int n, double weight, int window) {
+    const int R = (int)g->member.size();
+    int rc;
+    for (int r = 0; r < R; ++r) {
+        DeviceScope scope(g->device[r]);
+        if ((rc = wait_for_cut_planes(g, r))) return rc;
+        if ((rc = fdtd3d_pair_part_observed(g->member[r], n, FDTD3D_PART_EDGE, weight, window, r + 1 < R, g->run[r]))) return rc;
+        if ((rc = record(g, g->edge_done[r], g->run[r]))) return rc;
+    }
+    if ((rc = exchange_cut_planes(g))) return rc;
+    g->exchanged_once = true;
+    for (int r = 0; r < R; ++r) {
+        DeviceScope scope(g->device[r]);
+        if ((rc = fdtd3d_pair_part_observed(g->member[r], n, FDTD3D_PART_INTERIOR, weight, window, r + 1 < R, g->run[r]))) return rc;
+    }
+    for (int r = 0; r < R; ++r) {
+        DeviceScope scope(g->device[r]);
+        if (r + 1 < R) FDTD_HIP(hipStreamWaitEvent(g->run[r], arrival(g, false, r + 1), 0));
+        if ((rc = fdtd3d_observe_finish_pair(g->member[r], n, weight, window, r + 1 < R, g->run[r]))) return rc;
+    }
+    return FDTD_OK;
+}
 // One step on overlapping slabs: the one-step kernel over everything a slab stores, then the same exchange.
 int step_single_overlapping(fdtd3d_group* g, int n) {
     const int R = (int)g->member.size();
@@ -375,6 +401,8 @@ int build_group(fdtd3d_group* g, const fdtd3d_desc* desc, int n_slabs, const int
     }
     g->pairs = want_pairs;
     if (g->pairs) {
+        for (int r = 0; r < n_slabs; ++r)       // observables are reported for the layers a slab answers for
+            if (int rc = fdtd3d_observe_set_range(g->member[r], g->lo[r], g->hi[r])) return rc;
         // what crosses a cut: D, B and the x- and y-face CPML state of both families
         for (int c = 0; c < 3; ++c) g->xchg_ids.push_back(FDTD3D_DX + c);
         for (int c = 0; c < 3; ++c) g->xchg_ids.push_back(FDTD3D_BX + c);
@@ -572,8 +600,9 @@ int fdtd3d_group_observe_rms_window(fdtd3d_group_handle g, double* host, size_t 
     return each_member(g, [&](fdtd3d_handle h) { return fdtd3d_observe_rms_window(h, host, n); });
 }
 // Steps with the RMS window of FDTD3D::run (FDTD3D.cpp:1089-1103) advanced after every one of them.  One slab: the
-// engine's own fdtd3d_step_observed (two steps per launch where that pays).  Several: step, accumulate on every slab,
-// and where a step completes a window every slab keeps it.
+// engine's own fdtd3d_step_observed (two steps per launch where that pays).  Several: on overlapping slabs two steps per
+// launch with the window advanced inside (step_pair_observed); else step, accumulate on every slab, and where a step
+// completes a window every slab keeps it.
 int fdtd3d_group_step_observed(fdtd3d_group_handle g, int n0, int count, double weight, int window) {
     if (!g) return fail(FDTD_ERR_ARG, "null group");
     if (window < 1 || n0 < 0) return fail(FDTD_ERR_ARG, "group_step_observed: bad window or step number");
@@ -581,7 +610,18 @@ int fdtd3d_group_step_observed(fdtd3d_group_handle g, int n0, int count, double 
         DeviceScope scope(g->device[0]);
         return fdtd3d_step_observed(g->member[0], n0, count, weight, window, g->run[0]);
     }
+    bool probed = false;
+    for (fdtd3d_handle m : g->member) {
+        int ns = 0, np = 0;
+        if (int rc = fdtd3d_probe_read(m, nullptr, 0, &ns, &np)) return rc;
+        probed = probed || np > 0;
+    }
     for (int n = n0; n < n0 + count; ++n) {
+        if (g->pairs && !probed && n + 2 <= n0 + count) {
+            if (int rc = step_pair_observed(g, n, weight, window)) return rc;
+            ++n;
+            continue;
+        }
         if (int rc = g->pairs ? step_single_overlapping(g, n) : (g->fused ? step_fused(g, n) : step_halves(g, n))) return rc;
         for (size_t r = 0; r < g->member.size(); ++r) {
             if (g->pairs) { DeviceScope scope(g->device[r]); if (int rc = wait_for_cut_planes(g, (int)r)) return rc; }      // the top layer's cells look at the plane above

@@ -70,6 +70,8 @@ struct K3 {
     T* acc_snap;
     T acc_w;
     int acc_flags;
+    int acc_defer_kl;  // local plane of a cell layer whose SECOND-step contribution the launch leaves out (-1: none): the top layer of a
+                       // slab below another one, whose second-step E above it is only exact after the planes beyond the cut have arrived
 };
 
 template <typename T, int V>

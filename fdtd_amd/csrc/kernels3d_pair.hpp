@@ -550,9 +550,11 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
                     const bool on = own && kl - 3 < ke && row_lt && km3 >= 0 && km3 < Nz;
                     const size_t rs = ((size_t)(kl - 3) * a.ny1 + j) * px + c0;
                     P out = acc_km2;
-                    if (flags & 2) out = zero_pack<T, V>();
+                    if (kl - 3 != ap->acc_defer_kl) {      // (a deferred layer keeps the window as its first step left it)
+                        if (flags & 2) out = zero_pack<T, V>();
 #pragma unroll
-                    for (int e = 0; e < V; ++e) out.v[e] = out.v[e] + c.v[e] * wgt;
+                        for (int e = 0; e < V; ++e) out.v[e] = out.v[e] + c.v[e] * wgt;
+                    }
                     if (on) stg<T, V>(ap->acc + rs, lc, out);
                 }
                 {

@@ -267,6 +267,18 @@ int fdtd3d_observe_rms(fdtd3d_handle h, double* host, size_t n);
  *                accumulate themselves (slab drivers): the accumulator as it stands becomes the kept window
  *                (no copy: the two arrays change roles), and the next accumulate must open a new window.
  *   rms_window:  host = sqrt(kept window), laid out like fdtd3d_observe_rms. */
+/* For drivers of overlapping slabs (see fdtd3d_pair_part):
+ *   set_range:          the layers [k_lo, k_hi) this engine reports observables for (inside what it stores; default: all
+ *                       it stores).  Before the first download.
+ *   pair_part_observed: fdtd3d_pair_part with the window advanced by both steps of the launch (`window` as in
+ *                       fdtd3d_step_observed).  defer_top != 0 (a slab with a neighbour above): the second step's
+ *                       contribution of the top reported layer is left out -- it needs E one layer further up, which is
+ *                       exact only once the planes beyond the cut have arrived.
+ *   finish_pair:        after those planes have arrived: adds the deferred contribution (one-layer launch of the
+ *                       observe kernel) and, if the launch's second step completed a window, keeps it. */
+int fdtd3d_observe_set_range(fdtd3d_handle h, int k_lo, int k_hi);
+int fdtd3d_pair_part_observed(fdtd3d_handle h, int n, int part, double weight, int window, int defer_top, void* stream);
+int fdtd3d_observe_finish_pair(fdtd3d_handle h, int n, double weight, int window, int defer_top, void* stream);
 int fdtd3d_step_observed(fdtd3d_handle h, int n0, int count, double weight, int window, void* stream);
 int fdtd3d_observe_keep_window(fdtd3d_handle h);
 int fdtd3d_observe_rms_window(fdtd3d_handle h, double* host, size_t n);

@@ -200,7 +200,7 @@ def test_group_events_are_recorded_on_streams_of_their_own_slab(monkeypatch):
 
 
 def test_group_two_step_launches_with_observed_steps_and_resume(monkeypatch):
-    """Overlapping slabs: pairs, a single step, pairs again, observed steps (one step per launch there), a download of
+    """Overlapping slabs: pairs, a single step, pairs again, observed steps, a download of
     everything, an upload into a fresh group and more pairs -- every array equals the twin's throughout."""
     monkeypatch.setenv("FDTD_PAIR", "1")
     meta, ins, _, _ = util.load_fixture("g1_3d_cpml")
@@ -265,3 +265,41 @@ def test_group_planes_travel_by_rccl(mode, pairs, monkeypatch):
     plain = group_from_meta(meta, 32, 2, mode)
     assert L.fdtd3d_group_transport(plain.h) == 0
     plain.close()
+
+
+@pytest.mark.parametrize("name", ["g1_3d_cpml", "g2_3d_cavity"])
+@pytest.mark.parametrize("prec", [32, 64])
+@pytest.mark.parametrize("n_slabs,window", [(2, 4), (3, 5), (3, 1)])
+def test_group_window_inside_two_step_launches_on_slabs(name, prec, n_slabs, window, monkeypatch):
+    """Overlapping slabs with the RMS window advanced inside their two-step launches: a slab below another one leaves
+    the second step's contribution of its top layer out and adds it once the planes from above have arrived.  Both
+    windows (accumulating, last completed), the frame and every array equal the twin's, through runs of odd and even
+    length that start on odd and even steps."""
+    monkeypatch.setenv("FDTD_PAIR", "1")
+    meta, ins, _, _ = util.load_fixture(name)
+    g = group_from_meta(meta, prec, n_slabs, E.MODE_FUSED)
+    assert g.pairs
+    tw = util.twin3d_from_meta(meta, prec)
+    util.feed(g, ins)
+    util.feed(tw, ins)
+    n, kept = 0, None
+    for count in (1, 6, 7, 2, 8):
+        g.step_observed(n, count, 0.2, window)
+        for m in range(n, n + count):
+            tw.step(m, 1)
+            tw.observe_accumulate(0.2, m % window == 0)
+            if (m + 1) % window == 0:
+                kept = tw.observe_rms().copy()
+        n += count
+        if n % window != 0:
+            util.assert_equal_arrays(g.observe_rms(), tw.observe_rms(), f"{name} x{n_slabs}: window being accumulated after step {n - 1}")
+        if kept is not None:
+            util.assert_equal_arrays(g.observe_rms_window(), kept, f"{name} x{n_slabs}: last completed window after step {n - 1}")
+    a, b = g.observe_frame()
+    ta, tb = tw.observe_frame()
+    util.assert_equal_arrays(a, ta, "centred Ex")
+    util.assert_equal_arrays(b, tb, "|E|")
+    for id_ in po.FIELDS3D + po.ALL_PHI3D:
+        if g.size(id_):
+            util.assert_equal_arrays(g.get(id_), tw.get(id_), f"{name} x{n_slabs}: array {id_} after {n} observed steps")
+    g.close()

@@ -68,6 +68,22 @@ def test_fdtd3d_driver_with_the_window_inside_two_step_launches(tmp_path):
     assert "Ex_t00007.vti" in names and "Ex_t00035.vti" in names
 
 
+def test_fdtd3d_driver_on_overlapping_slabs_with_the_window_inside_the_launches(tmp_path):
+    """FDTD3D_SLABS with FDTD_PAIR=1: slabs that overlap by one layer either side of a cut, two steps per launch, the RMS
+    window advanced inside the launches (the top layer of a slab finished after the planes from above have arrived) --
+    the reference's files, byte for byte."""
+    fx = os.path.join(util.GOLDEN, "run3d")
+    meta = json.load(open(os.path.join(fx, "meta.json")))
+    env = dict(FDTD3D_NX=meta["N"][0], FDTD3D_NY=meta["N"][1], FDTD3D_NZ=meta["N"][2], FDTD3D_NPML=meta["npml"][0],
+               FDTD3D_STEPS=meta["steps"], FDTD3D_PRECISION=64, FDTD_PAIR=1)
+    for slabs in (2, 3):
+        out = _run("fdtd3d", dict(env, FDTD3D_SLABS=slabs), str(tmp_path))
+        assert f"{slabs} z-slabs" in out
+        _compare_dir(str(tmp_path / "output_3d"), fx)
+    _run("fdtd3d", dict(env, FDTD3D_SLABS=2, FDTD_GROUP_TRANSPORT="rccl"), str(tmp_path))      # the planes by ncclSend / ncclRecv
+    _compare_dir(str(tmp_path / "output_3d"), fx)
+
+
 def test_fdtd3d_driver_full_storage_and_fp32(tmp_path):
     fx = os.path.join(util.GOLDEN, "run3d")
     meta = json.load(open(os.path.join(fx, "meta.json")))

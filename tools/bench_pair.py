@@ -24,6 +24,7 @@ ap.add_argument("--split", type=int, default=0, help="two-step launches as edge 
 ap.add_argument("--check", type=int, default=1)
 ap.add_argument("--probes", type=int, default=0, help="register this many E probes, each on a plane of its own")
 ap.add_argument("--npml", default="0", help="layers on every face, or six numbers x-,x+,y-,y+,z-,z+")
+ap.add_argument("--noise", type=int, default=0, help="time a state with every cell of D and B non-zero (counter-hash noise)")
 a = ap.parse_args()
 a.npml = tuple(int(v) for v in a.npml.split(",")) if "," in a.npml else (int(a.npml),) * 6
 K = fs.constants(); d = (1053e-9 / 20,) * 3; dt = d[0] / (K["c0"] * 2)
@@ -39,6 +40,10 @@ def make():
     wf, mag = fs.default_source3d(N[0], N[1], 4096, d, dt)
     eng.set(E.JX_WF, wf); eng.set(E.JX_MAG, mag)
     eng.fill_materials(1234, K["eps0"], 4 * K["eps0"], K["mu0"], (2 if a.mu else 1) * K["mu0"])
+    if a.noise:
+        for c in range(3):
+            eng.fill_array(E.DX + c, 7, -1e-11, 1e-11)
+            eng.fill_array(E.BX + c, 7, -1e-8, 1e-8)
     for q in range(a.probes):
         eng.probe_add(E.EX + q % 3, N[0] // 2, N[1] // 3, (q + 1) * N[2] // (a.probes + 1))
     return eng
