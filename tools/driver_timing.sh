@@ -12,3 +12,5 @@ run FDTD3D_PRECISION=32
 run FDTD3D_PRECISION=32 FDTD3D_STEP_BY_STEP=1
 run FDTD3D_NX=1024 FDTD3D_NY=1024 FDTD3D_NZ=1024 FDTD3D_PRECISION=32 FDTD3D_STEPS=101 FDTD3D_FRAME_EVERY=100
 run FDTD3D_NX=1024 FDTD3D_NY=1024 FDTD3D_NZ=1024 FDTD3D_PRECISION=32 FDTD3D_STEPS=101 FDTD3D_FRAME_EVERY=100 FDTD3D_STEP_BY_STEP=1
+run FDTD3D_NX=1024 FDTD3D_NY=1024 FDTD3D_NZ=1024 FDTD3D_PRECISION=32 FDTD3D_STEPS=101 FDTD3D_FRAME_EVERY=100 FDTD3D_SLABS=2
+run FDTD3D_NX=1024 FDTD3D_NY=1024 FDTD3D_NZ=1024 FDTD3D_PRECISION=32 FDTD3D_STEPS=101 FDTD3D_FRAME_EVERY=100 FDTD3D_SLABS=2 FDTD_GROUP_TRANSPORT=rccl
