@@ -135,8 +135,8 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
     const unsigned lc = (unsigned)(i0 - c0);             // this lane's columns relative to the tile's base
     const bool own_x = live && (wrap ? ((int)lane < a.wrap_l ? col + V <= a.wrap_l * V - 2 : col >= a.wrap_r0 + 2)
                                      : ((c0 == 0 || col >= c0 + 2) && col + V <= c0 + TW - 2 && (a.wrap_l == 0 || col < a.wrap_r0 + 2)));
-    const bool wall_r = wrap ? lane == kLanes - 1 : col + V >= px;      // (the right part ends in the zero padding, or at the wall)
-    const bool first = i0 == 0;
+    const bool wall_r0 = wrap ? lane == kLanes - 1 : col + V >= px;     // (the right part ends in the zero padding, or at the wall)
+    const bool first0 = i0 == 0;
     const int jr = by * (W - 3) - 1 + w;
     const bool row_ok = jr >= 0 && jr < a.ny1;
     const int j = jr < 0 ? 0 : (jr < a.ny1 ? jr : a.ny1 - 1);
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
     else if (bz < a.znb[0] + a.znb[1]) { kb = a.zcut[0] + (bz - a.znb[0]) * a.zchunk[1]; ke = min(kb + a.zchunk[1], a.zcut[1]); }
     else { kb = a.zcut[1] + (bz - a.znb[0] - a.znb[1]) * a.zchunk[2]; ke = min(kb + a.zchunk[2], a.kl1); }
     const size_t sz = (size_t)a.ny1 * px;
-    const bool row_lt = j < Ny, row_in = j >= 1 && j < Ny;
+    const bool row_lt0 = j < Ny, row_in0 = j >= 1 && j < Ny;
     const T cy = a.dtd[1], cz = a.dtd[2], dt = a.dt;
     // A workgroup none of whose cells, in any of the four stages, comes near a CPML layer runs the loop compiled
     // without the layer code (the straight-line loop of a grid without CPML); the others the general one.
@@ -162,15 +162,27 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
     }
     // One loop per combination of layer families a workgroup can meet (x strips, y layers, z layers): each only carries
     // the code and the scalar state of its own families.
-    auto run = [&](auto lx_tag, auto ly_tag, auto lz_tag) {
+    // A wave whose cells all lie strictly inside the grid -- its row between the wall rows, its columns clear of both
+    // walls and of the row's end, its planes (all four stages, every iteration) between the wall planes -- runs the
+    // loop compiled with INNER: every "does this term exist here" test of the general loop is true there and every
+    // zone the plain one, so the tests and the selects the compiler makes of them (52 v_cndmask, 23 branches and about
+    // 80 scalar mask operations per iteration) are gone.  The waves of a workgroup may differ in this: both loops have
+    // the same iterations and barriers.
+    // (row Ny-1 and plane Nz-1 are not inner: the B update leaves the last cell along an axis out when its high face has no
+    // CPML layers, FDTD3D.cpp:822-823)
+    const bool inner_wave = row_ok && j >= 1 && j < Ny - 1 && !wrap && c0 > 0 && c0 + TW < px && kb + a.zoff >= 2 && ke + 2 + a.zoff < Nz;
+    auto run = [&](auto lx_tag, auto ly_tag, auto lz_tag, auto inner_tag) {
         constexpr bool LX = PML && decltype(lx_tag)::value, LY = PML && decltype(ly_tag)::value, LZ = PML && decltype(lz_tag)::value;
         constexpr bool LAYERS = LX || LY || LZ;
+        constexpr bool INNER = !LAYERS && decltype(inner_tag)::value;
+        const bool row_lt = INNER || row_lt0, row_in = INNER || row_in0, first = !INNER && first0, wall_r = !INNER && wall_r0;
+        const bool has_below = INNER || j >= 1;
         // a loop that carries exactly one family knows which one a non-zero family selector means
         constexpr int ONLY = (LX && !LY && !LZ) ? 1 : ((LY && !LX && !LZ) ? 2 : ((LZ && !LX && !LY) ? 3 : 0));
         auto fam_is = [](int fam, int q) -> bool { return ONLY ? (ONLY == q && fam != 0) : fam == q; };
         int lye, lyh;
-        const int zye = zone_e(j, Ny, a.np[1][0], a.np[1][1], lye);
-        const int zyh = zone_h(j, Ny, a.np[1][0], a.np[1][1], true, lyh);
+        const int zye = INNER ? (lye = 0, (int)Z_MID) : zone_e(j, Ny, a.np[1][0], a.np[1][1], lye);
+        const int zyh = INNER ? (lyh = 0, (int)Z_MID) : zone_h(j, Ny, a.np[1][0], a.np[1][1], true, lyh);
         const bool in_n = LX && a.np[0][0] > 0 && i0 < a.xwn;
         const bool in_p = LX && a.np[0][1] > 0 && i0 >= a.xp0 && i0 < a.xp0 + a.xwp;
         const bool wave_x = LX && __ballot(in_n || in_p) != 0;                       // some lane of this wave lies in an x strip
@@ -206,7 +218,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
         auto mid_of = [&](int mpar, int term) -> T* { return ap->pair_scr + mid_off + (size_t)(mpar * 12 + term) * TW; };
 
         auto h_of = [&](const P& b, const P& m) -> P { return MU ? divide<T, V>(b, m) : divide<T, V>(b, a.mu0); };
-        auto left_of_tile = [&](T shifted) -> T { return (lane == 0 && c0 == 0) ? (T)0 : shifted; };
+        auto left_of_tile = [&](T shifted) -> T { return (!INNER && lane == 0 && c0 == 0) ? (T)0 : shifted; };
         auto right_of_tile = [&](T shifted) -> T { return wall_r ? (T)0 : shifted; };
 
         // ---- the two kinds of term.  step 0: state from the old buffers into `mid`; step 1: from `mid` into the new buffers.
@@ -300,8 +312,8 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
         auto update_d = [&](P* dd, const P& hx, const P& hy, const P& hz, const P& hx_m, const P& hy_m, const P& hx_jm, const P& hz_jm,
                             T hy_l, T hz_l, int kp, int k, int step, int mpar, bool st, int fam, const P& pre0, const P& pre1) {
             int lke;
-            const int zke = zone_e(k, Nz, a.np[2][0], a.np[2][1], lke);
-            const bool pl_lt = k >= 0 && k < Nz, pl_in = k >= 1 && k < Nz;
+            const int zke = INNER ? (lke = 0, (int)Z_MID) : zone_e(k, Nz, a.np[2][0], a.np[2][1], lke);
+            const bool pl_lt = INNER || (k >= 0 && k < Nz), pl_in = INNER || (k >= 1 && k < Nz);
             const int kpc = kp < a.nzp ? kp : a.nzp - 1;
             auto terms = [&](auto fast) {
                 if (row_lt) uterm(fast, Minus{}, dd[0], diff<T, V>(hy, hy_m), false, zke, lke, AxZ{}, 0, cz, step, ap->phE[0][2], ap->phEn[0][2], kpc, 0, mpar, st, fam_is(fam, 3), pre0);
@@ -331,8 +343,8 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
         auto update_b = [&](P* bb, const P* e, const P* e_kp, const P& ex_jp, const P& ez_jp, T ey_r, T ez_r,
                             int kp, int km, int step, int mpar, bool st, int fam, const P& pre0, const P& pre1) {
             int lkh;
-            const int zkh = zone_h(km, Nz, a.np[2][0], a.np[2][1], true, lkh);
-            const bool bl_lt = km >= 0 && km < Nz, bl_in = km >= 1 && km < Nz;
+            const int zkh = INNER ? (lkh = 0, (int)Z_MID) : zone_h(km, Nz, a.np[2][0], a.np[2][1], true, lkh);
+            const bool bl_lt = INNER || (km >= 0 && km < Nz), bl_in = INNER || (km >= 1 && km < Nz);
             const int kpc = kp < 0 ? 0 : (kp < a.nzp ? kp : a.nzp - 1);
             auto terms = [&](auto fast) {
                 if (row_lt && bl_lt) {
@@ -400,7 +412,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
             // travel while the other waves do arithmetic; the stage in front of the next iteration's loads comes second
             // (measured at 1024^3 with CPML, four runs each: 11.10-11.14 ms per step against 11.20-11.27 without).
             __builtin_amdgcn_s_setprio(3);
-            const int klc = kl < a.nzp ? kl : a.nzp - 1;          // iterations past the last plane only drain the pipeline
+            const int klc = (INNER || kl < a.nzp) ? kl : a.nzp - 1;          // iterations past the last plane only drain the pipeline
             const size_t ro = ((size_t)klc * a.ny1 + j) * px + c0;
             const int k = kl + a.zoff;
             const int par = kl & 1;
@@ -418,7 +430,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
 #pragma unroll
                 for (int c = 0; c < 3; ++c) mu_[c] = zero_pack<T, V>();
             }
-            const size_t rj = j >= 1 ? ro - px : ro;
+            const size_t rj = has_below ? ro - px : ro;
             const P b0j = ldg<T, V>(ap->B[0] + rj, lc), b2j = ldg<T, V>(ap->B[2] + rj, lc);
             P m0j = zero_pack<T, V>(), m2j = zero_pack<T, V>();
             if (MU) { m0j = ldg<T, V>(ap->mu[0] + rj, lc); m2j = ldg<T, V>(ap->mu[2] + rj, lc); }
@@ -434,7 +446,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
 
             const P hx = h_of(bo[0], mu_[0]), hy = h_of(bo[1], mu_[1]), hz = h_of(bo[2], mu_[2]);
             P hx_jm = zero_pack<T, V>(), hz_jm = zero_pack<T, V>();
-            if (j >= 1) { hx_jm = h_of(b0j, m0j); hz_jm = h_of(b2j, m2j); }
+            if (has_below) { hx_jm = h_of(b0j, m0j); hz_jm = h_of(b2j, m2j); }
             {
                 const T hy_l = left_of_tile(lane_below(hy.v[V - 1])), hz_l = left_of_tile(lane_below(hz.v[V - 1]));
                 update_d(d1, hx, hy, hz, hx_km, hy_km, hx_jm, hz_jm, hy_l, hz_l, kl, k, 0, par, false, famA, preA0, preA1);
@@ -475,7 +487,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
                 asm volatile("" : "+s"(ap));
                 const T* dn = slot(h1s, par, w_dn);                  // H1(k-1) of the row below, published before the barrier
                 P hx_jm1 = lds_ld<T, V>(dn), hz_jm1 = lds_ld<T, V>(dn + TW);
-                if (j < 1) { hx_jm1 = zero_pack<T, V>(); hz_jm1 = zero_pack<T, V>(); }
+                if (!has_below) { hx_jm1 = zero_pack<T, V>(); hz_jm1 = zero_pack<T, V>(); }
                 const T hy_l = left_of_tile(lane_below(h1[1].v[V - 1])), hz_l = left_of_tile(lane_below(h1[2].v[V - 1]));
                 const int km = k - 1;
                 const bool st = own && kl - 1 < ke;
@@ -485,7 +497,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
                     const size_t rs = ro - sz * (size_t)(klc - (kl - 1));
                     stg_nt<T, V>(ap->Dn[0] + rs, lc, d2[0]);
                     if (row_lt) stg_nt<T, V>(ap->Dn[1] + rs, lc, d2[1]);
-                    if (km >= 0 && km < Nz) stg_nt<T, V>(ap->Dn[2] + rs, lc, d2[2]);
+                    if (INNER || (km >= 0 && km < Nz)) stg_nt<T, V>(ap->Dn[2] + rs, lc, d2[2]);
                 }
 #pragma unroll
                 for (int c = 0; c < 3; ++c) e2[c] = divide<T, V>(d2[c], ep_km[c]);
@@ -499,7 +511,7 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
                 const P ex_jp = lds_ld<T, V>(up), ez_jp = lds_ld<T, V>(up + TW);
                 const T ey_r = right_of_tile(lane_above(e2_km2[1].v[0])), ez_r = right_of_tile(lane_above(e2_km2[2].v[0]));
                 const int km2 = k - 2;
-                const bool bl_lt = km2 >= 0 && km2 < Nz;
+                const bool bl_lt = INNER || (km2 >= 0 && km2 < Nz);
                 P b2[3] = {b1_km2[0], b1_km2[1], b1_km2[2]};
                 const bool st = own && (!ACC || kl - 2 < ke);        // (ACC: the loop runs one iteration longer)
                 update_b(b2, e2_km2, e2, ex_jp, ez_jp, ey_r, ez_r, kl - 2, km2, 1, par, st, famD, preD0, preD1);
@@ -578,13 +590,14 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
     };
     using No = std::false_type;
     using Yes = std::true_type;
-    if constexpr (!PML) run(No{}, No{}, No{});
+    auto plain = [&]() { if (inner_wave) run(No{}, No{}, No{}, Yes{}); else run(No{}, No{}, No{}, No{}); };
+    if constexpr (!PML) plain();
     else if (near_x) {
-        if (near_y) { if (near_z) run(Yes{}, Yes{}, Yes{}); else run(Yes{}, Yes{}, No{}); }
-        else { if (near_z) run(Yes{}, No{}, Yes{}); else run(Yes{}, No{}, No{}); }
+        if (near_y) { if (near_z) run(Yes{}, Yes{}, Yes{}, No{}); else run(Yes{}, Yes{}, No{}, No{}); }
+        else { if (near_z) run(Yes{}, No{}, Yes{}, No{}); else run(Yes{}, No{}, No{}, No{}); }
     } else {
-        if (near_y) { if (near_z) run(No{}, Yes{}, Yes{}); else run(No{}, Yes{}, No{}); }
-        else { if (near_z) run(No{}, No{}, Yes{}); else run(No{}, No{}, No{}); }
+        if (near_y) { if (near_z) run(No{}, Yes{}, Yes{}, No{}); else run(No{}, Yes{}, No{}, No{}); }
+        else { if (near_z) run(No{}, No{}, Yes{}, No{}); else plain(); }
     }
 }
 
