@@ -72,6 +72,24 @@ __global__ void calib_sparse8(const char* p, size_t n, float* sink) {
     keep(s, sink);
 }
 
+// R arrays read and W arrays written per cell, 8 bytes per lane, non-temporal stores: the mix of the two-step kernel
+// (12 arrays in, 6 out) without any arithmetic to speak of
+struct MixPtrs { const float2* in[12]; float2* out[6]; };
+template <int R, int W>
+__global__ void calib_mix(MixPtrs p, size_t n) {
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        float2 s = {0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < R; ++r) { const float2 v = p.in[r][i]; s.x += v.x; s.y += v.y; }
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            typedef float vec2 __attribute__((ext_vector_type(2)));
+            vec2 o = {s.x + float(w), s.y};
+            __builtin_nontemporal_store(o, reinterpret_cast<vec2*>(&p.out[w][i]));
+        }
+    }
+}
+
 template <typename F>
 static void timed(const char* name, double asked, double l128, double b64, double b32, F launch) {
     hipEvent_t e0, e1;
@@ -119,6 +137,21 @@ int main() {
     timed("calib_sparse8<128>", B / 16, B, B / 2, B / 4, [&] { calib_sparse8<128><<<256 * 16, threads>>>(buf, kBytes / 128, sink); });
     timed("calib_sparse8<64>", B / 8, B, B, B / 2, [&] { calib_sparse8<64><<<256 * 16, threads>>>(buf, kBytes / 64, sink); });
     timed("calib_sparse8<32>", B / 4, B, B, B, [&] { calib_sparse8<32><<<256 * 16, threads>>>(buf, kBytes / 32, sink); });
+    {
+        // 18 arrays of 256 MiB, each at the start of a 1 GiB allocation of its own
+        MixPtrs mp;
+        void* blocks[18];
+        const size_t each = size_t(256) << 20;
+        for (int q = 0; q < 18; ++q) { CHECK(hipMalloc(&blocks[q], size_t(1) << 30)); CHECK(hipMemset(blocks[q], 0, each)); }
+        for (int q = 0; q < 12; ++q) mp.in[q] = reinterpret_cast<const float2*>(blocks[q]);
+        for (int q = 0; q < 6; ++q) mp.out[q] = reinterpret_cast<float2*>(blocks[12 + q]);
+        const double E = double(each);
+        timed("calib_mix<12,6>", 18 * E, 18 * E, 18 * E, 18 * E, [&] { calib_mix<12, 6><<<256 * 16, threads>>>(mp, each / 8); });
+        timed("calib_mix<6,6>", 12 * E, 12 * E, 12 * E, 12 * E, [&] { calib_mix<6, 6><<<256 * 16, threads>>>(mp, each / 8); });
+        timed("calib_mix<12,0>", 12 * E, 12 * E, 12 * E, 12 * E, [&] { calib_mix<12, 0><<<256 * 16, threads>>>(mp, each / 8); });
+        CHECK(hipDeviceSynchronize());
+        for (int q = 0; q < 18; ++q) CHECK(hipFree(blocks[q]));
+    }
     CHECK(hipDeviceSynchronize());
     CHECK(hipFree(buf));
     CHECK(hipFree(sink));
