@@ -170,7 +170,10 @@ __global__ void __launch_bounds__(kLanes * 16) __attribute__((amdgpu_waves_per_e
     // the same iterations and barriers.
     // (row Ny-1 and plane Nz-1 are not inner: the B update leaves the last cell along an axis out when its high face has no
     // CPML layers, FDTD3D.cpp:822-823)
-    const bool inner_wave = row_ok && j >= 1 && j < Ny - 1 && !wrap && c0 > 0 && c0 + TW < px && kb + a.zoff >= 2 && ke + 2 + a.zoff < Nz;
+    // (nor is a chunk whose last iterations, which only drain the pipeline, would address planes past the stored ones:
+    // the top chunk of a slab below another one)
+    const bool inner_wave = row_ok && j >= 1 && j < Ny - 1 && !wrap && c0 > 0 && c0 + TW < px && kb + a.zoff >= 2 && ke + 2 + a.zoff < Nz &&
+                            ke + (ACC ? 2 : 1) < a.nzp;
     auto run = [&](auto lx_tag, auto ly_tag, auto lz_tag, auto inner_tag) {
         constexpr bool LX = PML && decltype(lx_tag)::value, LY = PML && decltype(ly_tag)::value, LZ = PML && decltype(lz_tag)::value;
         constexpr bool LAYERS = LX || LY || LZ;

@@ -86,6 +86,55 @@ def test_group_observables_and_probe(pair_env):
     util.assert_equal_arrays(g.owner(pk).probe_read()[:, 0], extra["probe"][:25], "group probe series")
 
 
+@pytest.mark.parametrize("prec,N,npml", [
+    (32, (300, 33, 44), (0,) * 6),                 # three x tiles of 124 columns, no CPML: the loop for waves strictly inside the grid
+    (32, (390, 45, 50), (6, 6, 5, 5, 4, 4)),       # with CPML: the workgroups clear of the layers run that loop
+    (64, (150, 33, 40), (0, 3, 2, 0, 0, 0)),       # fp64 tiles own 60 columns
+])
+@pytest.mark.parametrize("observed", [False, True])
+def test_group_two_steps_per_launch_on_grids_of_several_x_tiles(prec, N, npml, observed, monkeypatch):
+    """Overlapping slabs whose workgroups include waves strictly inside the grid in x, y and (globally) z: the top chunk
+    of a slab below another one ends at its last stored plane, which such a wave must not read past."""
+    monkeypatch.setenv("FDTD_PAIR", "1")
+    K = po.consts()
+    d = (5e-8, 6e-8, 7e-8)
+    dt = 5e-8 / (2 * K["c0"])
+    steps, kJ = 9, N[2] // 2 + 1
+    g = E.EngineGroup3D(N, npml, d, dt, K["mu0"], kJ, steps, 3, precision=prec, has_mu=True, mode=E.MODE_FUSED)
+    assert g.pairs
+    for m in g.members:
+        m.pair_shape(7, 9)
+    tw = po.Twin3D(prec, N, npml, d, dt, K["mu0"], kJ, steps, True)
+    rng = np.random.default_rng(77)
+    wf, mag = rng.standard_normal(steps), rng.random((N[0], N[1] + 1))
+    for be in (g, tw):
+        for a in range(3):
+            for s in range(2):
+                if npml[a * 2 + s]:
+                    tabs = po.cpml_face(npml[a * 2 + s], s, d[a], d[a], dt)
+                    for k in range(6):
+                        be.set(po.tab_id(a, s, k), tabs[k])
+        be.set(po.JX_WF, wf)
+        be.set(po.JX_MAG, mag)
+        be.fill_materials(5, K["eps0"], 4 * K["eps0"], K["mu0"], 3 * K["mu0"])
+    if observed:
+        g.step_observed(0, steps, 0.2, 4)
+        kept = None
+        for n in range(steps):
+            tw.step(n, 1)
+            tw.observe_accumulate(0.2, n % 4 == 0)
+            if (n + 1) % 4 == 0:
+                kept = tw.observe_rms().copy()
+        util.assert_equal_arrays(g.observe_rms_window(), kept, f"N={N}: last completed window")
+        util.assert_equal_arrays(g.observe_rms(), tw.observe_rms(), f"N={N}: window being accumulated")
+    else:
+        g.step(0, steps)
+        tw.step(0, steps)
+    for id_ in po.FIELDS3D:
+        util.assert_equal_arrays(g.get(id_), tw.get(id_), f"N={N} fp{prec} array {id_} after {steps} steps")
+    g.close()
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_group_random_configurations_equal_twin(seed, pair_env):
     from tests.test_gpu_fused import _random_case
