@@ -1,5 +1,6 @@
 // engine2d.hip -- host side of the 2-D engine: device state, array exchange, launches, C ABI.
 #include "kernels2d_fused.hpp"
+#include "kernels2d_pair.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -95,6 +96,14 @@ struct Engine2 : fdtd2d_engine {
     T* tmp_field = nullptr;
     T* xrow2_d = nullptr;
     int ntx2 = 0, chunk_f = 2;        // rows per wave in the fused kernel (2 is the optimum at 8192^2 with four stacked waves per workgroup)
+    // two steps per launch (k2_pair): flags of its row segments, the B-side CPML state's second buffers, and a second
+    // pair of sample and sum buffers per field (all allocated on the first two-step launch)
+    int ntx3 = 0, chunk_p = 32, pair_env = -1;
+    unsigned char* disp3_d = nullptr;
+    bool any_disp = false, pair_ready = false, pair_allocated = false;
+    T* pm_z2[2] = {nullptr, nullptr}; T* pm_x2[2] = {nullptr, nullptr};
+    T* Fx[3] = {nullptr, nullptr, nullptr}; T* Fy[3] = {nullptr, nullptr, nullptr};
+    T* Sx[3] = {nullptr, nullptr, nullptr}; T* Sy[3] = {nullptr, nullptr, nullptr};
     std::vector<double> tab_h;
     std::vector<T> Jy;
     bool remap_set = false;        // FDTD_XCD_REMAP given: it overrides the per-kernel default tile order
@@ -207,6 +216,12 @@ struct Engine2 : fdtd2d_engine {
                 if (np[0][s] && (rc = dalloc((void**)&ph_x2[s], ((size_t)nz1 * (s ? xwp : xwn) + px) * sizeof(T)))) return rc;
             }
             if ((rc = dalloc((void**)&disp2_d, (size_t)nz1 * ntx2 + 64))) return rc;
+            // x tiles of the two-step kernel: tile t owns the packs [62 t + 1, 62 t + 63) (tile 0 its first one as well)
+            const int packs = (d.Nx + V - 1) / V;
+            ntx3 = packs <= kLanes - 1 ? 1 : (packs - (kLanes - 1) + (kLanes - 2) - 1) / (kLanes - 2) + 1;
+            if ((rc = dalloc((void**)&disp3_d, (size_t)nz1 * ntx3 + 64))) return rc;
+            if (const char* e = getenv("FDTD_Z_CHUNK2D_PAIR")) { int c = atoi(e); if (c >= 1 && c <= 65536) chunk_p = c; }
+            if (const char* e = getenv("FDTD2D_PAIR")) pair_env = atoi(e) != 0 ? 1 : 0;
             if ((rc = dalloc((void**)&xrow2_d, (size_t)6 * px * sizeof(T)))) return rc;
             if ((rc = upload_tables())) return rc;
         }
@@ -332,10 +347,18 @@ struct Engine2 : fdtd2d_engine {
         }
         FDTD_HIP(hipMemcpy(m.dev, st.data(), st.size() * sizeof(T), hipMemcpyHostToDevice));
         if (m.dev2) FDTD_HIP(hipMemcpy(m.dev2, st.data(), st.size() * sizeof(T), hipMemcpyHostToDevice));
+        pair_ready = false;               // the two-step kernel's spare buffers take the new values over on its next launch
         if (fused && id >= FDTD2D_C1 && id <= FDTD2D_C3) {
             const size_t tiles = (size_t)nz1 * ntx2;
-            hipLaunchKernelGGL((k2_flags_fused<T, V>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, 0, C[0], C[1], C[2], disp2_d, px, nz1, ntx2);
+            hipLaunchKernelGGL((k2_flags_fused<T, V>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, 0, C[0], C[1], C[2], disp2_d, px, nz1, ntx2, kLanes - 1);
             FDTD_HIP(hipGetLastError());
+            const size_t tiles3 = (size_t)nz1 * ntx3;
+            hipLaunchKernelGGL((k2_flags_fused<T, V>), dim3((unsigned)((tiles3 + 3) / 4)), dim3(256), 0, 0, C[0], C[1], C[2], disp3_d, px, nz1, ntx3, kLanes - 2);
+            FDTD_HIP(hipGetLastError());
+            std::vector<unsigned char> fl(tiles3);
+            FDTD_HIP(hipMemcpy(fl.data(), disp3_d, tiles3, hipMemcpyDeviceToHost));
+            any_disp = false;
+            for (unsigned char f : fl) any_disp = any_disp || f != 0;
         }
         if (id >= FDTD2D_C1 && id <= FDTD2D_C3) {
             const int ntx = px / (kLanes * V);
@@ -431,9 +454,95 @@ struct Engine2 : fdtd2d_engine {
         for (int f = 1; f < 3; ++f) { std::swap(Fa[f], Fb[f]); std::swap(Sa[f], Sb[f]); }
         return probe_record(s);
     }
+    // ---- two steps per launch
+    // Cells the kernels never write (rows and columns outside the sweeps, samples and sums of cells without Lorentz
+    // coefficients) must read the same from whichever buffer is current, so the spare buffers start as copies.
+    int pair_prepare() {
+        int rc;
+        if (!pair_allocated) {
+            const size_t fb = (fsize + px) * sizeof(T);
+            for (int sd = 0; sd < 2; ++sd) {
+                if (np[1][sd] && (rc = dalloc((void**)&pm_z2[sd], ((size_t)np[1][sd] * px + px) * sizeof(T)))) return rc;
+                if (np[0][sd] && (rc = dalloc((void**)&pm_x2[sd], ((size_t)nz1 * (sd ? xwp : xwn) + px) * sizeof(T)))) return rc;
+            }
+            pair_allocated = true;
+            (void)fb;
+        }
+        if (any_disp && !Fx[0]) {
+            const size_t fb = (fsize + px) * sizeof(T);
+            for (int f = 0; f < 3; ++f)
+                if ((rc = dalloc((void**)&Fx[f], fb)) || (rc = dalloc((void**)&Fy[f], fb)) || (rc = dalloc((void**)&Sx[f], fb)) || (rc = dalloc((void**)&Sy[f], fb))) return rc;
+        }
+        for (int sd = 0; sd < 2; ++sd) {
+            if (pm_z2[sd]) FDTD_HIP(hipMemcpy(pm_z2[sd], ph_z[1][sd], (size_t)np[1][sd] * px * sizeof(T), hipMemcpyDeviceToDevice));
+            if (pm_x2[sd]) FDTD_HIP(hipMemcpy(pm_x2[sd], ph_x[1][sd], (size_t)nz1 * (sd ? xwp : xwn) * sizeof(T), hipMemcpyDeviceToDevice));
+        }
+        if (Fx[0])
+            for (int f = 0; f < 3; ++f) {
+                FDTD_HIP(hipMemcpy(Fy[f], Fa[f], fsize * sizeof(T), hipMemcpyDeviceToDevice));
+                FDTD_HIP(hipMemcpy(Fx[f], Fb[f], fsize * sizeof(T), hipMemcpyDeviceToDevice));
+                FDTD_HIP(hipMemcpy(Sy[f], Sa[f], fsize * sizeof(T), hipMemcpyDeviceToDevice));
+                FDTD_HIP(hipMemcpy(Sx[f], Sb[f], fsize * sizeof(T), hipMemcpyDeviceToDevice));
+            }
+        pair_ready = true;
+        return FDTD_OK;
+    }
+    // whether step() takes its steps two per launch: never with probes (a probe is sampled after every step); by default
+    // on grids of at least 4 Mi cells (smaller ones do not fill the chip with the two-step kernel's longer waves);
+    // FDTD2D_PAIR=0/1 decides otherwise
+    bool pair_wanted() const {
+        if (!fused || !probes.specs.empty() || pair_env == 0) return false;
+        return pair_env == 1 || fsize >= ((size_t)4 << 20);
+    }
+    int step_pair(int n, hipStream_t s) {
+        if (!pair_ready) { FDTD_HIP(hipStreamSynchronize(s)); if (int rc = pair_prepare()) return rc; }
+        K2P<T> a;
+        a.Dy = Dy; a.Bx = Bx; a.Bz = Bz; a.Dyn = Dy2; a.Bxn = Bx2; a.Bzn = Bz2;
+        for (int f = 0; f < 3; ++f) {
+            a.F1[f] = Fa[f]; a.F2[f] = Fb[f]; a.FX[f] = Fx[f]; a.FY[f] = Fy[f];
+            a.S1[f] = Sa[f]; a.S2[f] = Sb[f]; a.SX[f] = Sx[f]; a.SY[f] = Sy[f];
+        }
+        a.C1 = C[0]; a.C2 = C[1]; a.C3 = C[2];
+        for (int sd = 0; sd < 2; ++sd) {
+            a.pe_z[sd] = ph_z[0][sd]; a.pe_zn[sd] = ph_z2[sd]; a.pe_x[sd] = ph_x[0][sd]; a.pe_xn[sd] = ph_x2[sd];
+            a.pm_z[sd] = ph_z[1][sd]; a.pm_zn[sd] = pm_z2[sd]; a.pm_x[sd] = ph_x[1][sd]; a.pm_xn[sd] = pm_x2[sd];
+        }
+        a.tab = tab_d; a.xrow = xrow2_d; a.disp = disp3_d;
+        a.Nx = d.Nx; a.Nz = d.Nz; a.px = px; a.nz1 = nz1;
+        for (int ax = 0; ax < 2; ++ax) for (int sd = 0; sd < 2; ++sd) a.np[ax][sd] = np[ax][sd];
+        a.xwn = xwn; a.xwp = xwp; a.xp0 = xp0;
+        a.iJ = d.i_Jy; a.kJ = d.k_Jy;
+        const bool s1 = n >= 0 && n < (int)Jy.size(), s2 = n + 1 >= 0 && n + 1 < (int)Jy.size();
+        a.src_on = (s1 ? 1 : 0) | (s2 ? 2 : 0);
+        a.dt = (T)d.dt; a.dtd[0] = (T)(d.dt / d.dx); a.dtd[1] = (T)(d.dt / d.dz); a.mu0 = (T)d.mu0; a.eps0 = (T)d.eps0;
+        a.jy = s1 ? a.dt * Jy[n] : (T)0;
+        a.jy2 = s2 ? a.dt * Jy[n + 1] : (T)0;
+        a.chunk = chunk_p; a.ntx = ntx3;
+        a.nbx = (ntx3 + kPairTiles2D - 1) / kPairTiles2D;
+        a.nbz = (nz1 + chunk_p - 1) / chunk_p;
+        a.remap = remap_set ? remap : 0;
+        timer.begin(3, s);
+        hipLaunchKernelGGL(k2_pair<T>, dim3((unsigned)a.nbx * a.nbz), dim3(kLanes * kPairTiles2D), 0, s, a);
+        timer.end(s);
+        FDTD_HIP(hipGetLastError());
+        std::swap(Dy, Dy2); std::swap(Bx, Bx2); std::swap(Bz, Bz2);
+        for (int sd = 0; sd < 2; ++sd) {
+            std::swap(ph_z[0][sd], ph_z2[sd]); std::swap(ph_x[0][sd], ph_x2[sd]);
+            std::swap(ph_z[1][sd], pm_z2[sd]); std::swap(ph_x[1][sd], pm_x2[sd]);
+        }
+        if (Fx[0])
+            for (int f = 0; f < 3; ++f) {       // after the second step -> n-1, after the first -> n-2; the old pair is the next launch's spare
+                std::swap(Fa[f], Fy[f]); std::swap(Fb[f], Fx[f]);
+                std::swap(Sa[f], Sy[f]); std::swap(Sb[f], Sx[f]);
+            }
+        return FDTD_OK;
+    }
     int step(int n0, int count, hipStream_t s) override {
         if (fused) {
-            for (int n = n0; n < n0 + count; ++n) if (int rc = step_fused(n, s)) return rc;
+            int n = n0;
+            if (pair_wanted())
+                for (; n + 1 < n0 + count; n += 2) if (int rc = step_pair(n, s)) return rc;
+            for (; n < n0 + count; ++n) if (int rc = step_fused(n, s)) return rc;
             return FDTD_OK;
         }
         for (int n = n0; n < n0 + count; ++n) {

@@ -226,10 +226,11 @@ __global__ void __launch_bounds__(kLanes * kStack2D) k2_fused(const K2F<T> a) {
     }
 }
 
-// Flags of the fused kernel's row segments: 64 packs starting every 63 packs.
+// Flags of overlapping row segments: 64 packs starting every `own_packs` packs (63 for the one-step fused kernel, 62 for
+// the two-step one).
 template <typename T, int V>
-__global__ void k2_flags_fused(const T* C1, const T* C2, const T* C3, unsigned char* disp, int px, int nz1, int ntx) {
-    constexpr int OWN = (kLanes - 1) * V;
+__global__ void k2_flags_fused(const T* C1, const T* C2, const T* C3, unsigned char* disp, int px, int nz1, int ntx, int own_packs) {
+    const int OWN = own_packs * V;
     const int lane = threadIdx.x & (kLanes - 1);
     const size_t tile = (size_t)blockIdx.x * (blockDim.x / kLanes) + (threadIdx.x >> 6);
     if (tile >= (size_t)nz1 * ntx) return;

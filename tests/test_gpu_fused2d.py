@@ -18,6 +18,17 @@ pytestmark = pytest.mark.gpu
 CURRENT = (po.D2_DY, po.D2_EY, po.D2_BX, po.D2_HX, po.D2_BZ, po.D2_HZ)
 
 
+@pytest.fixture(autouse=True, params=[None, 1, 3, 32], ids=["one-step", "two-step-chunk1", "two-step-chunk3", "two-step-chunk32"])
+def two_steps_per_launch(request, monkeypatch):
+    """Every test of this file also runs with fdtd2d_step taking its steps two per launch (k2_pair; grids this small
+    only do so when FDTD2D_PAIR=1 says so), in chunks of 1, 3 and 32 rows per wave: each must leave what single steps
+    leave, bit for bit -- fields, samples, polarisation sums and the CPML state of both sides."""
+    if request.param is not None:
+        monkeypatch.setenv("FDTD2D_PAIR", "1")
+        monkeypatch.setenv("FDTD_Z_CHUNK2D_PAIR", str(request.param))
+    return request.param
+
+
 def compare_2d(eng, ref_get, Nx, Nz, npml, mask, what):
     """mask: [Nx][Nz] bool, cells with a non-zero coefficient."""
     for id_ in po.FIELDS2D + po.ALL_PHI2D:
@@ -125,6 +136,30 @@ def test_fused2d_random_configurations_equal_twin(seed):
     eng.step(0, steps)
     tw.step(0, steps)
     compare_2d(eng, tw.get, Nx, Nz, npml, mask, f"seed {seed}: 2-D fused {Nx}x{Nz} npml={npml} fp{prec} source=({iJ},{kJ})")
+
+
+def test_two_step_launches_are_what_runs(two_steps_per_launch):
+    """7 steps = three launches of the two-step kernel and one of the one-step kernel when pairing is on, seven one-step
+    launches otherwise; with a probe registered every step is a launch of its own (a probe is sampled after every step)."""
+    meta, ins, _, _ = util.load_fixture("g4_2d_slab")
+    make = lambda: fdtd_amd.Engine2D(meta["Nx"], meta["Nz"], meta["npml"], meta["dx"], meta["dz"], meta["dt"], meta["mu0"], meta["eps0"],
+                                     meta["i_Jy"], meta["k_Jy"], meta["steps"], precision=32, mode=MODE2D_FUSED)
+    eng = make()
+    util.feed(eng, ins)
+    eng.kernel_timing(True)
+    eng.step(0, 7)
+    eng.kernel_timing(False)
+    pairs, singles = eng.kernel_time(3)[0], eng.kernel_time(2)[0]
+    assert (pairs, singles) == ((3, 1) if two_steps_per_launch is not None else (0, 7))
+    probed = make()
+    util.feed(probed, ins)
+    probed.probe_add(po.D2_DY, 3, 4)
+    probed.kernel_timing(True)
+    probed.step(0, 7)
+    probed.kernel_timing(False)
+    assert (probed.kernel_time(3)[0], probed.kernel_time(2)[0]) == (0, 7)
+    util.assert_equal_arrays(probed.get(po.D2_DY), eng.get(po.D2_DY), "Dy after 7 steps, with and without a probe")
+    assert probed.probe_read().shape[0] == 7
 
 
 def test_fused2d_observables_equal_twin():
