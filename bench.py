@@ -230,7 +230,7 @@ def roofline_block(eng, mode_name, has_mu, cells_local, steps, applies_traffic, 
 
 
 def _timed_steps(torch, eng, warm: int, steps: int):
-    """(wall seconds, device seconds of the step kernels) of `steps` steps after `warm` untimed ones."""
+    """(wall seconds, device seconds of the step kernels, launches per kind of kernel) of `steps` steps after `warm` untimed ones."""
     eng.step(0, warm)
     torch.cuda.synchronize()
     eng.kernel_timing(True)
@@ -239,8 +239,8 @@ def _timed_steps(torch, eng, warm: int, steps: int):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     eng.kernel_timing(False)
-    dev_ms = sum(eng.kernel_time(kind)[1] for kind in (0, 1, 2, 3))
-    return el, dev_ms * 1e-3
+    recs = [eng.kernel_time(kind) for kind in (0, 1, 2, 3)]
+    return el, sum(ms for _, ms in recs) * 1e-3, [n for n, _ in recs]
 
 
 def extra_legs_in_children(scale: str):
@@ -305,7 +305,7 @@ def extra_legs(torch, scale: str, only=None):
                 for c in range(3):        # timed on a state without zeros, like the headline
                     eng.fill_array(E.DX + c, 7, -1e-11, 1e-11)
                     eng.fill_array(E.BX + c, 7, -1e-8, 1e-8)
-                el, dev_s = _timed_steps(torch, eng, warm, steps)
+                el, dev_s, _ = _timed_steps(torch, eng, warm, steps)
                 cells = N[0] * N[1] * N[2]
                 bpc = words * (precision // 8)              # the reference formulation's bytes per cell and step
                 ss, cs = eng.sumsq(E.DX), eng.checksum(E.DX)
@@ -339,7 +339,7 @@ def extra_legs(torch, scale: str, only=None):
                 for q, c in enumerate(coef):
                     eng.set(E.D2_C1 + q, c)
                 del coef
-                el, dev_s = _timed_steps(torch, eng, warm, steps)
+                el, dev_s, launches = _timed_steps(torch, eng, warm, steps)
                 cells = N * N
                 alg = n_disp * 132 + (cells - n_disp) * 24      # dispersive cell 33 words, plain cell 6 words (fp32)
                 ss = eng.sumsq(E.D2_EY)
@@ -347,8 +347,8 @@ def extra_legs(torch, scale: str, only=None):
                                          + ("reference Lorentz slab (41 columns), plain elsewhere" if material == "slab" else "Lorentz-dispersive at every cell"),
                              "grid": [N, N], "dtype": "f32", "steps": steps, "warmup": warm, "ms_per_step": el / steps * 1e3,
                              "value": cells * steps / el / 1e6, "unit": "Mcell-updates/s", "kernel_ms_per_step": dev_s / steps * 1e3,
-                             "dispersive_cells": n_disp,
-                             "roofline": {"bound": "hbm", "kernel": "k2_fused", "algorithmic_bytes_per_launch": alg,
+                             "dispersive_cells": n_disp, "steps_per_launch": 2 if launches[3] else 1,
+                             "roofline": {"bound": "hbm", "kernel": "k2_pair" if launches[3] else "k2_fused", "algorithmic_bytes_per_step": alg,
                                           "algorithmic_bytes_per_dispersive_cell": 132, "algorithmic_bytes_per_plain_cell": 24,
                                           "achieved": alg * steps / dev_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": alg * steps / dev_s / 1e9 / HBM_PEAK_GBS},

@@ -77,6 +77,7 @@ namespace {
 template <typename T>
 struct Engine2 : fdtd2d_engine {
     static constexpr int V = VecWidth<T>::V;
+    static constexpr int PV = V / 2;          // elements per lane in the two-step kernel (8 bytes)
     int px = 0, nz1 = 0, np[2][2], xwn = 0, xwp = 0, xp0 = 0;
     size_t fsize = 0, bytes = 0;
     T* Dy = nullptr; T* Bx = nullptr; T* Bz = nullptr;
@@ -98,7 +99,7 @@ struct Engine2 : fdtd2d_engine {
     int ntx2 = 0, chunk_f = 2;        // rows per wave in the fused kernel (2 is the optimum at 8192^2 with four stacked waves per workgroup)
     // two steps per launch (k2_pair): flags of its row segments, the B-side CPML state's second buffers, and a second
     // pair of sample and sum buffers per field (all allocated on the first two-step launch)
-    int ntx3 = 0, chunk_p = 32, pair_env = -1;
+    int ntx3 = 0, chunk_p = 8, pair_env = -1;      // rows per wave: 8 is the optimum at 8192^2 (4-6: 0.30-0.32 ms per step, 8: 0.277, 12: 0.284, 19: 0.31, 38: 0.35)
     unsigned char* disp3_d = nullptr;
     bool any_disp = false, pair_ready = false, pair_allocated = false;
     T* pm_z2[2] = {nullptr, nullptr}; T* pm_x2[2] = {nullptr, nullptr};
@@ -216,9 +217,9 @@ struct Engine2 : fdtd2d_engine {
                 if (np[0][s] && (rc = dalloc((void**)&ph_x2[s], ((size_t)nz1 * (s ? xwp : xwn) + px) * sizeof(T)))) return rc;
             }
             if ((rc = dalloc((void**)&disp2_d, (size_t)nz1 * ntx2 + 64))) return rc;
-            // x tiles of the two-step kernel: tile t owns the packs [62 t + 1, 62 t + 63) (tile 0 its first one as well)
-            const int packs = (d.Nx + V - 1) / V;
-            ntx3 = packs <= kLanes - 1 ? 1 : (packs - (kLanes - 1) + (kLanes - 2) - 1) / (kLanes - 2) + 1;
+            // x tiles of the two-step kernel (8 bytes per lane): tile t owns the lanes [HL, 64 - HL) of its 64 (tile 0 its first ones as well)
+            const int packs = (d.Nx + PV - 1) / PV, own_lanes = kLanes - 2 * pair2d_halo_lanes<PV>(), reach = kLanes - pair2d_halo_lanes<PV>();
+            ntx3 = packs <= reach ? 1 : (packs - reach + own_lanes - 1) / own_lanes + 1;
             if ((rc = dalloc((void**)&disp3_d, (size_t)nz1 * ntx3 + 64))) return rc;
             if (const char* e = getenv("FDTD_Z_CHUNK2D_PAIR")) { int c = atoi(e); if (c >= 1 && c <= 65536) chunk_p = c; }
             if (const char* e = getenv("FDTD2D_PAIR")) pair_env = atoi(e) != 0 ? 1 : 0;
@@ -353,12 +354,11 @@ struct Engine2 : fdtd2d_engine {
             hipLaunchKernelGGL((k2_flags_fused<T, V>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, 0, C[0], C[1], C[2], disp2_d, px, nz1, ntx2, kLanes - 1);
             FDTD_HIP(hipGetLastError());
             const size_t tiles3 = (size_t)nz1 * ntx3;
-            hipLaunchKernelGGL((k2_flags_fused<T, V>), dim3((unsigned)((tiles3 + 3) / 4)), dim3(256), 0, 0, C[0], C[1], C[2], disp3_d, px, nz1, ntx3, kLanes - 2);
+            hipLaunchKernelGGL((k2_flags_fused<T, PV>), dim3((unsigned)((tiles3 + 3) / 4)), dim3(256), 0, 0, C[0], C[1], C[2], disp3_d, px, nz1, ntx3, kLanes - 2 * pair2d_halo_lanes<PV>());
             FDTD_HIP(hipGetLastError());
             std::vector<unsigned char> fl(tiles3);
             FDTD_HIP(hipMemcpy(fl.data(), disp3_d, tiles3, hipMemcpyDeviceToHost));
-            any_disp = false;
-            for (unsigned char f : fl) any_disp = any_disp || f != 0;
+            if (int rc = pair_tile_lists(fl)) return rc;
         }
         if (id >= FDTD2D_C1 && id <= FDTD2D_C3) {
             const int ntx = px / (kLanes * V);
@@ -455,6 +455,23 @@ struct Engine2 : fdtd2d_engine {
         return probe_record(s);
     }
     // ---- two steps per launch
+    // x tiles with and without Lorentz cells (any row): each kind gets a launch of its own kernel variant
+    int* tiles3_d = nullptr;
+    int n_plain3 = 0, n_lz3 = 0;
+    int pair_tile_lists(const std::vector<unsigned char>& flags) {
+        std::vector<int> plain, lz;
+        for (int t = 0; t < ntx3; ++t) {
+            bool any = false;
+            for (int k = 0; k < nz1 && !any; ++k) any = !flags.empty() && flags[(size_t)k * ntx3 + t] != 0;
+            (any ? lz : plain).push_back(t);
+        }
+        n_plain3 = (int)plain.size(); n_lz3 = (int)lz.size();
+        any_disp = n_lz3 > 0;
+        plain.insert(plain.end(), lz.begin(), lz.end());
+        if (!tiles3_d) if (int rc = dalloc((void**)&tiles3_d, (size_t)ntx3 * sizeof(int) + 64)) return rc;
+        FDTD_HIP(hipMemcpy(tiles3_d, plain.data(), plain.size() * sizeof(int), hipMemcpyHostToDevice));
+        return FDTD_OK;
+    }
     // Cells the kernels never write (rows and columns outside the sweeps, samples and sums of cells without Lorentz
     // coefficients) must read the same from whichever buffer is current, so the spare buffers start as copies.
     int pair_prepare() {
@@ -518,11 +535,18 @@ struct Engine2 : fdtd2d_engine {
         a.jy = s1 ? a.dt * Jy[n] : (T)0;
         a.jy2 = s2 ? a.dt * Jy[n + 1] : (T)0;
         a.chunk = chunk_p; a.ntx = ntx3;
-        a.nbx = (ntx3 + kPairTiles2D - 1) / kPairTiles2D;
         a.nbz = (nz1 + chunk_p - 1) / chunk_p;
         a.remap = remap_set ? remap : 0;
+        if (!tiles3_d) if (int rc = pair_tile_lists({})) return rc;       // (no coefficient was ever uploaded: no Lorentz cell)
         timer.begin(3, s);
-        hipLaunchKernelGGL(k2_pair<T>, dim3((unsigned)a.nbx * a.nbz), dim3(kLanes * kPairTiles2D), 0, s, a);
+        if (n_plain3) {
+            a.tiles = tiles3_d; a.n_tiles = n_plain3; a.nbx = (n_plain3 + kPairTiles2D - 1) / kPairTiles2D;
+            hipLaunchKernelGGL((k2_pair<T, PV, false>), dim3((unsigned)a.nbx * a.nbz), dim3(kLanes * kPairTiles2D), 0, s, a);
+        }
+        if (n_lz3) {
+            a.tiles = tiles3_d + n_plain3; a.n_tiles = n_lz3; a.nbx = (n_lz3 + kPairTiles2D - 1) / kPairTiles2D;
+            hipLaunchKernelGGL((k2_pair<T, PV, true>), dim3((unsigned)a.nbx * a.nbz), dim3(kLanes * kPairTiles2D), 0, s, a);
+        }
         timer.end(s);
         FDTD_HIP(hipGetLastError());
         std::swap(Dy, Dy2); std::swap(Bx, Bx2); std::swap(Bz, Bz2);

@@ -11,9 +11,11 @@
 // everything between lives in the wave's registers.  Per-cell arithmetic is the sequence of operations of the one-step
 // kernel, so the results are bit-identical to two of its steps.
 //
-// Nothing is exchanged between waves: an x tile's 64 packs overlap the next tile's by two (the first and the last pack
-// are computed, not stored -- two columns either side is what two steps reach), and a chunk of C rows takes C + 3
-// iterations.  A halo cell recomputes its first step from the OLD state after its owner may have stored the new one,
+// Nothing is exchanged between waves: an x tile's 64 lanes (8 bytes each: two fp32 or one fp64 column) overlap the next
+// tile's by two columns either side, which is what two steps reach (computed, not stored), and a chunk of C rows takes
+// C + 3 iterations.  Eight bytes per lane instead of the one-step kernel's sixteen keep the 17 packs a wave hands from
+// iteration to iteration (and with them the whole kernel) within 128 registers; the rows of the next iteration are
+// requested before the current one is computed.  A halo cell recomputes its first step from the OLD state after its owner may have stored the new one,
 // so everything the launch writes goes to other buffers than it reads: Dy, Bx, Bz, the CPML state of both sides, and
 // four buffers per sample / sum family (n-1 and n-2 in; after the first and after the second step out).  The CPML state
 // and the polarisation sum of a cell wait in registers between its two steps.
@@ -43,26 +45,33 @@ struct K2P {
     T jy, jy2, dt, dtd[2], mu0, eps0;
     int chunk, ntx, nbx, nbz, remap;
     const unsigned char* disp;                     // [nz1][ntx]: any Lorentz coefficient non-zero in the 64 packs of that wave
+    const int* tiles; int n_tiles;                 // the x tiles this launch covers
 };
 template <typename T> using ArgBlock2P = const FDTD_AS(4) K2P<T>*;
 
 constexpr int kPairTiles2D = 4;      // waves (= neighbouring x tiles of one chunk of rows) per workgroup
 
-template <typename T>
+// lanes at either end of a wave that are computed but not stored: two columns
+template <int V> constexpr int pair2d_halo_lanes() { return V >= 2 ? 1 : 2; }
+
+// LZ = false: for x tiles none of whose row segments holds a Lorentz cell -- the kernel without the recursion, its
+// loads and its registers (more waves per SIMD); the tiles that do hold such cells go through LZ = true in a launch of their own.
+template <typename T, int V, bool LZ>
 __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a) {
-    constexpr int V = VecWidth<T>::V;
-    constexpr int OWN = (kLanes - 2) * V;                // columns a wave owns (tile 0 owns its first pack as well)
+    constexpr int HL = pair2d_halo_lanes<V>();
+    constexpr int OWN = (kLanes - 2 * HL) * V;           // columns a wave owns (tile 0 owns its first lanes as well)
     using P = Pack<T, V>;
     ArgBlock2P<T> ap = (ArgBlock2P<T>)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & (kLanes - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned bid = a.remap > 1 ? xcd_grouped(blockIdx.x, gridDim.x, (unsigned)a.remap) : blockIdx.x;
-    const int tx = (int)(bid % a.nbx) * kPairTiles2D + w, bz = (int)(bid / a.nbx);
-    if (tx >= a.ntx) return;                             // (no barrier in this kernel)
+    const int ti = (int)(bid % a.nbx) * kPairTiles2D + w, bz = (int)(bid / a.nbx);
+    if (ti >= a.n_tiles) return;                         // (no barrier in this kernel)
+    const int tx = __builtin_amdgcn_readfirstlane(a.tiles[ti]);
     const int c0 = tx * OWN, i0 = c0 + lane * V;
     const int px = a.px, Nz = a.Nz, nz1 = a.nz1;
     const bool valid = i0 < px;                          // the last tile may reach past the row
-    const bool own_lane = valid && lane < kLanes - 1 && (lane >= 1 || tx == 0);
+    const bool own_lane = valid && lane < kLanes - HL && (lane >= HL || tx == 0);
     const unsigned lo = valid ? lane * V : 0;            // lanes past the row re-read the tile's first pack and are zeroed
     const bool first = i0 == 0;
     const bool in_n = valid && a.np[0][0] > 0 && i0 < a.xwn;
@@ -75,7 +84,7 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
     const bool src_lane = valid && a.iJ >= i0 && a.iJ < i0 + V;
     const T dt = a.dt, cz = a.dtd[1];
 
-    auto flag_of = [&](int k) -> bool { return k >= 0 && k < nz1 && __builtin_amdgcn_readfirstlane((int)a.disp[(size_t)k * a.ntx + tx]) != 0; };
+    auto flag_of = [&](int k) -> bool { return LZ && k >= 0 && k < nz1 && __builtin_amdgcn_readfirstlane((int)a.disp[(size_t)k * a.ntx + tx]) != 0; };
     auto layer = [](int zone) -> bool { return zone == Z_NEG || zone == Z_POS; };
     // one z term (the zone is the row's, the same for the whole wave): plain between the layers, or inside them
     //   phi = b*phi + a*curl;  d += C*curl + dt*phi   (FDTD2D.cpp:300-316 pattern) with the state handed in and out through `ph`
@@ -136,17 +145,33 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
     P e1_km = zero_pack<T, V>(), d1_km = e1_km, bx0_km = e1_km, bz0_km = e1_km, s1e_km = e1_km, pez_km = e1_km, pex_km = e1_km;      // row k-1 after the first step's D half
     P h1x_km2 = e1_km, h1z_km2 = e1_km, e2_km2 = e1_km, b1x_km2 = e1_km, b1z_km2 = e1_km, sh1x_km2 = e1_km, sh1z_km2 = e1_km, pmz_km2 = e1_km, pmx_km2 = e1_km;   // row k-2
     bool fl_km = flag_of(kb - 2), fl_km2 = false;
+    // "any Lorentz cell in this row segment": fetched one row ahead, with the rows themselves, so that no iteration starts
+    // by waiting for its flag
+    unsigned char pf = 0;
+    auto request_flag = [&](int k) { if constexpr (LZ) pf = (k >= 0 && k < nz1) ? a.disp[(size_t)k * a.ntx + tx] : (unsigned char)0; };
+    request_flag(kb - 1);
+    // Dy, Bx, Bz of the row the next iteration starts with
+    P nd = zero_pack<T, V>(), nbx = nd, nbz = nd;
+    auto request_row = [&](int k) {
+        if (k >= 0 && k < nz1) {
+            const size_t q = (size_t)k * px + c0;
+            nd = ldg<T, V>(ap->Dy + q, lo); nbx = ldg<T, V>(ap->Bx + q, lo); nbz = ldg<T, V>(ap->Bz + q, lo);
+        }
+    };
+    request_row(kb - 1);
 
     for (int k = kb - 1; k <= ke + 1; ++k) {
         asm volatile("" : "+s"(ap));
-        const bool fl_k = flag_of(k);
+        const bool fl_k = LZ && __builtin_amdgcn_readfirstlane((int)pf) != 0;
         const size_t ro = (size_t)(k < 0 ? 0 : (k < nz1 ? k : nz1 - 1)) * px + c0;        // uniform offset of row k's segment (clamped: rows outside are not touched)
         const int km = k - 1, km2 = k - 2;
+        const P cur_d = nd, cur_bx = nbx, cur_bz = nbz;
+        if (k < ke + 1) { request_row(k + 1); request_flag(k + 1); }
 
         // ---------------------------------------------------------------- A: row k, first step: H0, Dy1, Ey1
         P d1 = zero_pack<T, V>(), e1 = d1, hx0 = d1, bx0 = d1, bz0 = d1, s1e = d1, pez = d1, pex = d1;
         if (k >= 0 && k < nz1) {
-            d1 = ldg<T, V>(ap->Dy + ro, lo); bx0 = ldg<T, V>(ap->Bx + ro, lo); bz0 = ldg<T, V>(ap->Bz + ro, lo);
+            d1 = cur_d; bx0 = cur_bx; bz0 = cur_bz;
             if (!valid) { d1 = zero_pack<T, V>(); bx0 = d1; bz0 = d1; }
             hx0 = field_of<T, V>(bx0, a.mu0, fl_k, ap->F1[1] + ro, ap->C1 + ro, ap->C2 + ro, ap->C3 + ro, lo);
             P hz0 = field_of<T, V>(bz0, a.mu0, fl_k, ap->F1[2] + ro, ap->C1 + ro, ap->C2 + ro, ap->C3 + ro, lo);
@@ -166,7 +191,7 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
                 for (int e = 0; e < V; ++e) if (i0 + e == a.iJ) d1.v[e] = d1.v[e] - a.jy;
             }
             if (k < Nz) {
-                if (fl_k) {
+                if (LZ && fl_k) {
                     const P c1 = ldg<T, V>(ap->C1 + ro, lo), c2 = ldg<T, V>(ap->C2 + ro, lo), c3 = ldg<T, V>(ap->C3 + ro, lo);
                     const P f1 = ldg<T, V>(ap->F1[0] + ro, lo), f2 = ldg<T, V>(ap->F2[0] + ro, lo), s1 = ldg<T, V>(ap->S1[0] + ro, lo), s2 = ldg<T, V>(ap->S2[0] + ro, lo);
 #pragma unroll
@@ -193,7 +218,7 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
                 pmx = ld_x(ap->pm_x, (size_t)km * a.xwn + c0, (ptrdiff_t)((size_t)km * a.xwp) + (c0 - a.xp0));
                 xterm(b1z, diff_fwd_x<T, V>(e1_km, e1_r), xCm, a.xrow + 3 * (size_t)px + c0, pmx);
             }
-            if (fl_km) {
+            if (LZ && fl_km) {
                 const P c1 = ldg<T, V>(ap->C1 + q, lo), c2 = ldg<T, V>(ap->C2 + q, lo), c3 = ldg<T, V>(ap->C3 + q, lo);
                 {
                     const P f1 = ldg<T, V>(ap->F1[1] + q, lo), f2 = ldg<T, V>(ap->F2[1] + q, lo), s1 = ldg<T, V>(ap->S1[1] + q, lo), s2 = ldg<T, V>(ap->S2[1] + q, lo);
@@ -239,7 +264,7 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
                 }
                 if (st) stg_nt<T, V>(ap->Dyn + q, lo, d2);
                 if (km < Nz) {
-                    if (fl_km) {
+                    if (LZ && fl_km) {
                         const P c1 = ldg<T, V>(ap->C1 + q, lo), c2 = ldg<T, V>(ap->C2 + q, lo), c3 = ldg<T, V>(ap->C3 + q, lo);
                         const P f2 = ldg<T, V>(ap->F1[0] + q, lo), s2 = ldg<T, V>(ap->S1[0] + q, lo);
                         P s2e;
@@ -269,7 +294,7 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
                 if (own_lane) st_x(ap->pm_xn, (size_t)km2 * a.xwn + c0, (ptrdiff_t)((size_t)km2 * a.xwp) + (c0 - a.xp0), pmx_km2);
             }
             if (own_lane) { stg_nt<T, V>(ap->Bxn + q, lo, b2x); stg_nt<T, V>(ap->Bzn + q, lo, b2z); }
-            if (fl_km2) {
+            if (LZ && fl_km2) {
                 const P c1 = ldg<T, V>(ap->C1 + q, lo), c2 = ldg<T, V>(ap->C2 + q, lo), c3 = ldg<T, V>(ap->C3 + q, lo);
                 P fn, sn;
                 {
