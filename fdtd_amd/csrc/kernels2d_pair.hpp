@@ -20,6 +20,7 @@
 // four buffers per sample / sum family (n-1 and n-2 in; after the first and after the second step out).  The CPML state
 // and the polarisation sum of a cell wait in registers between its two steps.
 #pragma once
+#include <type_traits>
 #include "kernels2d_fused.hpp"
 
 namespace fdtd {
@@ -70,28 +71,37 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
     const int tx = __builtin_amdgcn_readfirstlane(a.tiles[ti]);
     const int c0 = tx * OWN, i0 = c0 + lane * V;
     const int px = a.px, Nz = a.Nz, nz1 = a.nz1;
-    const bool valid = i0 < px;                          // the last tile may reach past the row
-    const bool own_lane = valid && lane < kLanes - HL && (lane >= HL || tx == 0);
-    const unsigned lo = valid ? lane * V : 0;            // lanes past the row re-read the tile's first pack and are zeroed
-    const bool first = i0 == 0;
-    const bool in_n = valid && a.np[0][0] > 0 && i0 < a.xwn;
-    const bool in_p = valid && a.np[0][1] > 0 && i0 >= a.xp0 && i0 < a.xp0 + a.xwp;
+    const bool valid0 = i0 < px;                         // the last tile may reach past the row
+    const bool own_lane0 = valid0 && lane < kLanes - HL && (lane >= HL || tx == 0);
+    const unsigned lo = valid0 ? lane * V : 0;           // lanes past the row re-read the tile's first pack and are zeroed
+    const bool first0 = i0 == 0;
+    const bool in_n0 = valid0 && a.np[0][0] > 0 && i0 < a.xwn;
+    const bool in_p0 = valid0 && a.np[0][1] > 0 && i0 >= a.xp0 && i0 < a.xp0 + a.xwp;
     P xCe = ldg<T, V>(a.xrow + 2 * (size_t)px + c0, lo), xCm = ldg<T, V>(a.xrow + 5 * (size_t)px + c0, lo);
-    if (!valid) { xCe = zero_pack<T, V>(); xCm = xCe; }
+    if (!valid0) { xCe = zero_pack<T, V>(); xCm = xCe; }
     const T* face_z = a.tab + (size_t)(1 * 2) * 6 * kMaxLayers;
     const int kb = bz * a.chunk, ke = min(kb + a.chunk, nz1);
     if (kb >= nz1) return;
-    const bool src_lane = valid && a.iJ >= i0 && a.iJ < i0 + V;
+    const bool src_lane0 = valid0 && a.iJ >= i0 && a.iJ < i0 + V;
     const T dt = a.dt, cz = a.dtd[1];
+    // A wave none of whose cells, in any of the four stages, meets a wall, a CPML layer, the end of the row or the source
+    // row runs the loop compiled with INNER: every "does this term exist here" test is true there and every zone the plain
+    // one, so the tests and the selects the compiler makes of them are gone.
+    const bool inner_wave = tx > 0 && c0 + kLanes * V <= px && (a.np[0][0] == 0 || c0 >= a.xwn) && (a.np[0][1] == 0 || c0 + kLanes * V <= a.xp0) &&
+                            kb >= max(2, a.np[1][0] + 2) && ke <= Nz - a.np[1][1] - 2 && !(a.src_on && a.kJ >= kb - 1 && a.kJ <= ke + 1);
+    auto run = [&](auto inner_tag) {
+    constexpr bool INNER = decltype(inner_tag)::value;
+    const bool valid = INNER || valid0, own_lane = INNER ? (lane >= HL && lane < kLanes - HL) : own_lane0;
+    const bool first = !INNER && first0, in_n = !INNER && in_n0, in_p = !INNER && in_p0, src_lane = !INNER && src_lane0;
 
     auto flag_of = [&](int k) -> bool { return LZ && k >= 0 && k < nz1 && __builtin_amdgcn_readfirstlane((int)a.disp[(size_t)k * a.ntx + tx]) != 0; };
     auto layer = [](int zone) -> bool { return zone == Z_NEG || zone == Z_POS; };
     // one z term (the zone is the row's, the same for the whole wave): plain between the layers, or inside them
     //   phi = b*phi + a*curl;  d += C*curl + dt*phi   (FDTD2D.cpp:300-316 pattern) with the state handed in and out through `ph`
     auto zterm = [&](P& d, const P& curl, int zone, int l, int kb3, P& ph) {
-        if (zone == Z_NONE) return;
+        if (!INNER && zone == Z_NONE) return;
         const T d0 = d.v[0];
-        if (zone == Z_MID) {
+        if (INNER || zone == Z_MID) {
 #pragma unroll
             for (int e = 0; e < V; ++e) d.v[e] = d.v[e] + cz * curl.v[e];
         } else {
@@ -137,7 +147,7 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
 
     // ---- state handed from iteration to iteration
     P hx0_km = zero_pack<T, V>();                                    // H0x(k-1)
-    if (kb - 2 >= 0) {
+    if (INNER || kb - 2 >= 0) {
         const size_t q = (size_t)(kb - 2) * px + c0;
         hx0_km = field_of<T, V>(ldg<T, V>(ap->Bx + q, lo), a.mu0, flag_of(kb - 2), ap->F1[1] + q, ap->C1 + q, ap->C2 + q, ap->C3 + q, lo);
         if (!valid) hx0_km = zero_pack<T, V>();
@@ -153,7 +163,7 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
     // Dy, Bx, Bz of the row the next iteration starts with
     P nd = zero_pack<T, V>(), nbx = nd, nbz = nd;
     auto request_row = [&](int k) {
-        if (k >= 0 && k < nz1) {
+        if (INNER || (k >= 0 && k < nz1)) {
             const size_t q = (size_t)k * px + c0;
             nd = ldg<T, V>(ap->Dy + q, lo); nbx = ldg<T, V>(ap->Bx + q, lo); nbz = ldg<T, V>(ap->Bz + q, lo);
         }
@@ -163,34 +173,34 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
     for (int k = kb - 1; k <= ke + 1; ++k) {
         asm volatile("" : "+s"(ap));
         const bool fl_k = LZ && __builtin_amdgcn_readfirstlane((int)pf) != 0;
-        const size_t ro = (size_t)(k < 0 ? 0 : (k < nz1 ? k : nz1 - 1)) * px + c0;        // uniform offset of row k's segment (clamped: rows outside are not touched)
+        const size_t ro = (size_t)(INNER ? k : (k < 0 ? 0 : (k < nz1 ? k : nz1 - 1))) * px + c0;        // uniform offset of row k's segment (clamped: rows outside are not touched)
         const int km = k - 1, km2 = k - 2;
         const P cur_d = nd, cur_bx = nbx, cur_bz = nbz;
         if (k < ke + 1) { request_row(k + 1); request_flag(k + 1); }
 
         // ---------------------------------------------------------------- A: row k, first step: H0, Dy1, Ey1
         P d1 = zero_pack<T, V>(), e1 = d1, hx0 = d1, bx0 = d1, bz0 = d1, s1e = d1, pez = d1, pex = d1;
-        if (k >= 0 && k < nz1) {
+        if (INNER || (k >= 0 && k < nz1)) {
             d1 = cur_d; bx0 = cur_bx; bz0 = cur_bz;
             if (!valid) { d1 = zero_pack<T, V>(); bx0 = d1; bz0 = d1; }
             hx0 = field_of<T, V>(bx0, a.mu0, fl_k, ap->F1[1] + ro, ap->C1 + ro, ap->C2 + ro, ap->C3 + ro, lo);
             P hz0 = field_of<T, V>(bz0, a.mu0, fl_k, ap->F1[2] + ro, ap->C1 + ro, ap->C2 + ro, ap->C3 + ro, lo);
             if (!valid) { hx0 = zero_pack<T, V>(); hz0 = hx0; }
             T hz_l = lane_below(hz0.v[V - 1]);
-            if (lane == 0) hz_l = (T)0;                  // tile 0: the wall; other tiles: lane 0 is a halo pack whose first column nobody uses
+            if (!INNER && lane == 0) hz_l = (T)0;        // tile 0: the wall; other tiles: lane 0 is a halo pack whose first column nobody uses
             int lk;
-            const int zk = zone_e(k, Nz, a.np[1][0], a.np[1][1], lk);
-            if (layer(zk)) pez = ldg<T, V>(ap->pe_z[zk == Z_POS] + ((size_t)lk * px + c0), lo);
+            const int zk = INNER ? (lk = 0, (int)Z_MID) : zone_e(k, Nz, a.np[1][0], a.np[1][1], lk);
+            if (!INNER && layer(zk)) pez = ldg<T, V>(ap->pe_z[zk == Z_POS] + ((size_t)lk * px + c0), lo);
             zterm(d1, diff<T, V>(hx0, hx0_km), zk, lk, 0, pez);
-            if (k >= 1 && k < Nz) {
-                pex = ld_x(ap->pe_x, (size_t)k * a.xwn + c0, (ptrdiff_t)((size_t)k * a.xwp) + (c0 - a.xp0));
+            if (INNER || (k >= 1 && k < Nz)) {
+                if (!INNER) pex = ld_x(ap->pe_x, (size_t)k * a.xwn + c0, (ptrdiff_t)((size_t)k * a.xwp) + (c0 - a.xp0));
                 xterm(d1, diff_back_x<T, V>(hz0, hz_l), xCe, a.xrow + c0, pex);
             }
-            if ((a.src_on & 1) && k == a.kJ && src_lane) {
+            if (!INNER && (a.src_on & 1) && k == a.kJ && src_lane) {
 #pragma unroll
                 for (int e = 0; e < V; ++e) if (i0 + e == a.iJ) d1.v[e] = d1.v[e] - a.jy;
             }
-            if (k < Nz) {
+            if (INNER || k < Nz) {
                 if (LZ && fl_k) {
                     const P c1 = ldg<T, V>(ap->C1 + ro, lo), c2 = ldg<T, V>(ap->C2 + ro, lo), c3 = ldg<T, V>(ap->C3 + ro, lo);
                     const P f1 = ldg<T, V>(ap->F1[0] + ro, lo), f2 = ldg<T, V>(ap->F2[0] + ro, lo), s1 = ldg<T, V>(ap->S1[0] + ro, lo), s2 = ldg<T, V>(ap->S2[0] + ro, lo);
@@ -207,15 +217,15 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
         // ---------------------------------------------------------------- B: row k-1, first step: B1, H1
         const T e1_r = lane_above(e1_km.v[0]);            // (taken with all lanes active)
         P b1x = bx0_km, b1z = bz0_km, h1x = zero_pack<T, V>(), h1z = h1x, sh1x = h1x, sh1z = h1x, pmz = h1x, pmx = h1x;
-        if (k >= kb && km >= 0 && km < Nz) {
+        if (k >= kb && (INNER || (km >= 0 && km < Nz))) {
             asm volatile("" : "+s"(ap));
             const size_t q = (size_t)km * px + c0;
             int lm;
-            const int zm = zone_h(km, Nz, a.np[1][0], a.np[1][1], false, lm);
-            if (layer(zm)) pmz = ldg<T, V>(ap->pm_z[zm == Z_POS] + ((size_t)lm * px + c0), lo);
+            const int zm = INNER ? (lm = 0, (int)Z_MID) : zone_h(km, Nz, a.np[1][0], a.np[1][1], false, lm);
+            if (!INNER && layer(zm)) pmz = ldg<T, V>(ap->pm_z[zm == Z_POS] + ((size_t)lm * px + c0), lo);
             zterm(b1x, diff<T, V>(e1, e1_km), zm, lm, 3, pmz);
-            if (km >= 1) {
-                pmx = ld_x(ap->pm_x, (size_t)km * a.xwn + c0, (ptrdiff_t)((size_t)km * a.xwp) + (c0 - a.xp0));
+            if (INNER || km >= 1) {
+                if (!INNER) pmx = ld_x(ap->pm_x, (size_t)km * a.xwn + c0, (ptrdiff_t)((size_t)km * a.xwp) + (c0 - a.xp0));
                 xterm(b1z, diff_fwd_x<T, V>(e1_km, e1_r), xCm, a.xrow + 3 * (size_t)px + c0, pmx);
             }
             if (LZ && fl_km) {
@@ -244,26 +254,26 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
         P e2 = zero_pack<T, V>();
         {
             T hz_l = lane_below(h1z.v[V - 1]);
-            if (lane == 0) hz_l = (T)0;
-            if (k >= kb + 1 && km < nz1) {
+            if (!INNER && lane == 0) hz_l = (T)0;
+            if (k >= kb + 1 && (INNER || km < nz1)) {
                 asm volatile("" : "+s"(ap));
                 const size_t q = (size_t)km * px + c0;
                 const bool st = own_lane && km >= kb && km < ke;
                 P d2 = d1_km;
                 int lk;
-                const int zk = zone_e(km, Nz, a.np[1][0], a.np[1][1], lk);
+                const int zk = INNER ? (lk = 0, (int)Z_MID) : zone_e(km, Nz, a.np[1][0], a.np[1][1], lk);
                 zterm(d2, diff<T, V>(h1x, h1x_km2), zk, lk, 0, pez_km);
-                if (layer(zk) && st) stg<T, V>(ap->pe_zn[zk == Z_POS] + ((size_t)lk * px + c0), lo, pez_km);
-                if (km >= 1 && km < Nz) {
+                if (!INNER && layer(zk) && st) stg<T, V>(ap->pe_zn[zk == Z_POS] + ((size_t)lk * px + c0), lo, pez_km);
+                if (INNER || (km >= 1 && km < Nz)) {
                     xterm(d2, diff_back_x<T, V>(h1z, hz_l), xCe, a.xrow + c0, pex_km);
-                    if (st) st_x(ap->pe_xn, (size_t)km * a.xwn + c0, (ptrdiff_t)((size_t)km * a.xwp) + (c0 - a.xp0), pex_km);
+                    if (!INNER && st) st_x(ap->pe_xn, (size_t)km * a.xwn + c0, (ptrdiff_t)((size_t)km * a.xwp) + (c0 - a.xp0), pex_km);
                 }
-                if ((a.src_on & 2) && km == a.kJ && src_lane) {
+                if (!INNER && (a.src_on & 2) && km == a.kJ && src_lane) {
 #pragma unroll
                     for (int e = 0; e < V; ++e) if (i0 + e == a.iJ) d2.v[e] = d2.v[e] - a.jy2;
                 }
                 if (st) stg_nt<T, V>(ap->Dyn + q, lo, d2);
-                if (km < Nz) {
+                if (INNER || km < Nz) {
                     if (LZ && fl_km) {
                         const P c1 = ldg<T, V>(ap->C1 + q, lo), c2 = ldg<T, V>(ap->C2 + q, lo), c3 = ldg<T, V>(ap->C3 + q, lo);
                         const P f2 = ldg<T, V>(ap->F1[0] + q, lo), s2 = ldg<T, V>(ap->S1[0] + q, lo);
@@ -281,17 +291,17 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
 
         // ---------------------------------------------------------------- D: row k-2, second step: B2, H2
         const T e2_r = lane_above(e2_km2.v[0]);
-        if (km2 >= kb && km2 < ke && km2 < Nz) {
+        if (km2 >= kb && km2 < ke && (INNER || km2 < Nz)) {
             asm volatile("" : "+s"(ap));
             const size_t q = (size_t)km2 * px + c0;
             int lm;
-            const int zm = zone_h(km2, Nz, a.np[1][0], a.np[1][1], false, lm);
+            const int zm = INNER ? (lm = 0, (int)Z_MID) : zone_h(km2, Nz, a.np[1][0], a.np[1][1], false, lm);
             P b2x = b1x_km2, b2z = b1z_km2;
             zterm(b2x, diff<T, V>(e2, e2_km2), zm, lm, 3, pmz_km2);
-            if (layer(zm) && own_lane) stg<T, V>(ap->pm_zn[zm == Z_POS] + ((size_t)lm * px + c0), lo, pmz_km2);
-            if (km2 >= 1) {
+            if (!INNER && layer(zm) && own_lane) stg<T, V>(ap->pm_zn[zm == Z_POS] + ((size_t)lm * px + c0), lo, pmz_km2);
+            if (INNER || km2 >= 1) {
                 xterm(b2z, diff_fwd_x<T, V>(e2_km2, e2_r), xCm, a.xrow + 3 * (size_t)px + c0, pmx_km2);
-                if (own_lane) st_x(ap->pm_xn, (size_t)km2 * a.xwn + c0, (ptrdiff_t)((size_t)km2 * a.xwp) + (c0 - a.xp0), pmx_km2);
+                if (!INNER && own_lane) st_x(ap->pm_xn, (size_t)km2 * a.xwn + c0, (ptrdiff_t)((size_t)km2 * a.xwp) + (c0 - a.xp0), pmx_km2);
             }
             if (own_lane) { stg_nt<T, V>(ap->Bxn + q, lo, b2x); stg_nt<T, V>(ap->Bzn + q, lo, b2z); }
             if (LZ && fl_km2) {
@@ -318,6 +328,8 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
         e1_km = e1; d1_km = d1; bx0_km = bx0; bz0_km = bz0; s1e_km = s1e; pez_km = pez; pex_km = pex;
         fl_km2 = fl_km; fl_km = fl_k;
     }
+    };
+    if (inner_wave) run(std::true_type{}); else run(std::false_type{});
 }
 
 }  // namespace fdtd
