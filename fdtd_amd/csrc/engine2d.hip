@@ -111,7 +111,11 @@ struct Engine2 : fdtd2d_engine {
     int chunk = 1, remap = 1;      // rows per wave: at 8192^2 one row per wave is fastest (the row below comes from L2, and more waves are in flight)
     std::vector<void*> allocs;
 
-    ~Engine2() override { for (void* p : allocs) (void)hipFree(p); probes.release(); timer.release(); }
+    ~Engine2() override {
+        if (lz_stream) { (void)hipStreamSynchronize(lz_stream); (void)hipStreamDestroy(lz_stream); (void)hipEventDestroy(lz_fork); (void)hipEventDestroy(lz_join); }
+        for (void* p : allocs) (void)hipFree(p);
+        probes.release(); timer.release();
+    }
 
     // ---- probe time series: the sample arrays change places every step, so a probe names a slot of
     // this table (0-2 Dy,Bx,Bz; 3-5 current sample; 6-8 older sample; 9-11 / 12-14 the same for S; 15-17 C)
@@ -458,6 +462,8 @@ struct Engine2 : fdtd2d_engine {
     // x tiles with and without Lorentz cells (any row): each kind gets a launch of its own kernel variant
     int* tiles3_d = nullptr;
     int n_plain3 = 0, n_lz3 = 0;
+    hipStream_t lz_stream = nullptr;
+    hipEvent_t lz_fork = nullptr, lz_join = nullptr;
     int pair_tile_lists(const std::vector<unsigned char>& flags) {
         std::vector<int> plain, lz;
         for (int t = 0; t < ntx3; ++t) {
@@ -538,15 +544,27 @@ struct Engine2 : fdtd2d_engine {
         a.nbz = (nz1 + chunk_p - 1) / chunk_p;
         a.remap = remap_set ? remap : 0;
         if (!tiles3_d) if (int rc = pair_tile_lists({})) return rc;       // (no coefficient was ever uploaded: no Lorentz cell)
+        // the tiles with Lorentz cells (usually few) run beside the others, on a stream of their own
+        const bool beside = n_plain3 > 0 && n_lz3 > 0;
+        if (beside && !lz_stream) {
+            FDTD_HIP(hipStreamCreateWithFlags(&lz_stream, hipStreamNonBlocking));
+            FDTD_HIP(hipEventCreateWithFlags(&lz_fork, hipEventDisableTiming));
+            FDTD_HIP(hipEventCreateWithFlags(&lz_join, hipEventDisableTiming));
+        }
         timer.begin(3, s);
+        if (n_lz3) {
+            hipStream_t ls = beside ? lz_stream : s;
+            if (beside) { FDTD_HIP(hipEventRecord(lz_fork, s)); FDTD_HIP(hipStreamWaitEvent(ls, lz_fork, 0)); }
+            K2P<T> b = a;
+            b.tiles = tiles3_d + n_plain3; b.n_tiles = n_lz3; b.nbx = (n_lz3 + kPairTiles2D - 1) / kPairTiles2D;
+            hipLaunchKernelGGL((k2_pair<T, PV, true>), dim3((unsigned)b.nbx * b.nbz), dim3(kLanes * kPairTiles2D), 0, ls, b);
+            if (beside) FDTD_HIP(hipEventRecord(lz_join, ls));
+        }
         if (n_plain3) {
             a.tiles = tiles3_d; a.n_tiles = n_plain3; a.nbx = (n_plain3 + kPairTiles2D - 1) / kPairTiles2D;
             hipLaunchKernelGGL((k2_pair<T, PV, false>), dim3((unsigned)a.nbx * a.nbz), dim3(kLanes * kPairTiles2D), 0, s, a);
         }
-        if (n_lz3) {
-            a.tiles = tiles3_d + n_plain3; a.n_tiles = n_lz3; a.nbx = (n_lz3 + kPairTiles2D - 1) / kPairTiles2D;
-            hipLaunchKernelGGL((k2_pair<T, PV, true>), dim3((unsigned)a.nbx * a.nbz), dim3(kLanes * kPairTiles2D), 0, s, a);
-        }
+        if (beside) FDTD_HIP(hipStreamWaitEvent(s, lz_join, 0));
         timer.end(s);
         FDTD_HIP(hipGetLastError());
         std::swap(Dy, Dy2); std::swap(Bx, Bx2); std::swap(Bz, Bz2);
