@@ -17,13 +17,14 @@ struct Sim2DConfig {
     int slab;              // 1: the reference's Lorentz slab, 0: no dispersive material
     int precision;
     bool fused;            // one kernel per step (Ey, Hx, Hz only stored at dispersive cells)
+    bool step_by_step;     // one engine call per step, as the reference's loop is written (for comparison: the engine then cannot take two steps per launch)
     int n_T0;              // steps per period: RMS window n_T0/2, weights 4/n_T0
     int frame_every;
     bool write_files;
     std::string out_dir;
     // The reference's hard-coded problem (FDTD2D.cpp:20-38, :60-65, FDTD2D.h:41).
     static Sim2DConfig reference_default();
-    // FDTD2D_NX / _NZ / _STEPS / _NPML / _IJY / _KJY / _SLAB / _PRECISION / _FRAME_EVERY / _FUSED / _WRITE / _OUT
+    // FDTD2D_NX / _NZ / _STEPS / _NPML / _IJY / _KJY / _SLAB / _PRECISION / _FRAME_EVERY / _FUSED / _STEP_BY_STEP / _WRITE / _OUT
     void apply_environment();
 };
 

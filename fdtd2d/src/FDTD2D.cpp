@@ -2,6 +2,7 @@
 // fdtd_engine.h, output cadence of the reference's run() (fdtd2d/src/FDTD2D.cpp:501-535).
 #include "FDTD2D.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -50,6 +51,7 @@ Sim2DConfig Sim2DConfig::reference_default() {
     c.slab = 1;
     c.precision = 64;
     c.fused = true;
+    c.step_by_step = false;
     c.n_T0 = static_cast<int>(std::round(cfl * cells_per_wavelength));
     c.frame_every = 20;
     c.write_files = true;
@@ -66,6 +68,7 @@ void Sim2DConfig::apply_environment() {
     if (env_int("FDTD2D_NPML", v)) for (int& n : n_pml) n = v;
     if (env_int("FDTD2D_WRITE", v)) write_files = v != 0;
     if (env_int("FDTD2D_FUSED", v)) fused = v != 0;
+    if (env_int("FDTD2D_STEP_BY_STEP", v)) step_by_step = v != 0;
     if (const char* e = std::getenv("FDTD2D_OUT")) if (*e) out_dir = e;
 }
 
@@ -134,18 +137,27 @@ void FDTD2D::run() {
     const Sim2DConfig& c = m_cfg;
     const int half_period = c.n_T0 / 2;
     const double weight = 4.0 / c.n_T0;
-    for (int n = 0; n < c.steps; ++n) {
+    // The reference looks at the fields after every step (FDTD2D.cpp:510-531): the RMS window is advanced, a completed
+    // window written out, every frame_every-th step dumped.  Here the steps between two of those moments go to the engine
+    // in one call, which advances the window on the device by itself (two steps per launch on large grids).  A run of
+    // steps ends at the next step whose field is dumped, and one step after the next step that completes a window at
+    // the latest -- the engine keeps a completed window until the next one completes.
+    const int every = c.frame_every > 0 ? c.frame_every : c.steps + 1;
+    for (int n = 0; n < c.steps;) {
         const auto t0 = std::chrono::steady_clock::now();
-        must(fdtd2d_step(m_engine, n, 1, nullptr), "step");
-        must(fdtd2d_observe_accumulate(m_engine, weight, n % half_period == 0, nullptr), "RMS window");
-        if ((n + 1) % half_period == 0) {
-            must(fdtd2d_observe_rms(m_engine, m_center.data(), m_center.size()), "RMS download");
-            if (m_out) m_out->write_csv(numbered("eymag_t", n + 1), m_center, c.Nx, c.Nz, c.dx, c.dz);
+        const int next_dump = (n + every - 1) / every * every;                                   // first step >= n that is dumped
+        const int next_done = (n + half_period) / half_period * half_period - 1;                 // first step >= n that completes a window
+        const int last = c.step_by_step ? n : std::min(std::min(next_dump, next_done + (half_period > 1 ? 1 : 0)), c.steps - 1);
+        must(fdtd2d_step_observed(m_engine, n, last - n + 1, weight, half_period, nullptr), "step");
+        if (next_done <= last) {
+            must(fdtd2d_observe_rms_window(m_engine, m_center.data(), m_center.size()), "RMS download");
+            if (m_out) m_out->write_csv(numbered("eymag_t", next_done + 1), m_center, c.Nx, c.Nz, c.dx, c.dz);
         }
-        if (n % c.frame_every == 0) {
-            dump_frame(n);
-            std::cout << "[n=" << n << "] frame dumped.\n";
+        if (last % every == 0) {
+            dump_frame(last);
+            std::cout << "[n=" << last << "] frame dumped.\n";
         }
+        n = last + 1;
         m_step_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     dump_frame(c.steps);

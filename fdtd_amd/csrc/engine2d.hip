@@ -63,6 +63,8 @@ struct fdtd2d_engine {
     virtual size_t device_bytes() = 0;
     virtual int observe_accumulate(double weight, int reset, hipStream_t s) = 0;
     virtual int observe_rms(double* host, size_t n) = 0;
+    virtual int step_observed(int n0, int count, double weight, int window, hipStream_t s) = 0;
+    virtual int observe_rms_window(double* host, size_t n) = 0;
     virtual int probe_add(int id, int i, int k) = 0;
     virtual int probe_record(hipStream_t s) = 0;
     virtual int probe_read(double* out, size_t cap, int* n_samples, int* n_probes) = 0;
@@ -253,14 +255,57 @@ struct Engine2 : fdtd2d_engine {
         FDTD_HIP(hipGetLastError());
         return FDTD_OK;
     }
+    int download_window(const T* src, double* host) {
+        FDTD_HIP(hipDeviceSynchronize());
+        std::vector<T> st(fsize);
+        FDTD_HIP(hipMemcpy(st.data(), src, st.size() * sizeof(T), hipMemcpyDeviceToHost));
+        for (int i = 0; i < d.Nx; ++i) for (int k = 0; k < d.Nz; ++k) host[(size_t)i * d.Nz + k] = std::sqrt((double)st[(size_t)k * px + i]);
+        return FDTD_OK;
+    }
     int observe_rms(double* host, size_t n) override {
         if (n != (size_t)d.Nx * d.Nz || !host) return fail(FDTD_ERR_ARG, "observe_rms: expected %zu values", (size_t)d.Nx * d.Nz);
         if (!obs_acc) return fail(FDTD_ERR_STATE, "observe_rms: nothing accumulated yet");
-        FDTD_HIP(hipDeviceSynchronize());
-        std::vector<T> st(fsize);
-        FDTD_HIP(hipMemcpy(st.data(), obs_acc, st.size() * sizeof(T), hipMemcpyDeviceToHost));
-        for (int i = 0; i < d.Nx; ++i) for (int k = 0; k < d.Nz; ++k) host[(size_t)i * d.Nz + k] = std::sqrt((double)st[(size_t)k * px + i]);
+        return download_window(obs_acc, host);
+    }
+    // ---- the loop body of FDTD2D::run (FDTD2D.cpp:510-522) for a run of steps: step, advance the window, keep a
+    // window that completes.  Steps that go two per launch advance the window inside the launch.
+    T* obs_snap = nullptr;
+    bool obs_have_window = false;
+    T pair_acc_w = (T)0;
+    int pair_acc_flags = -1;          // (-1: the next two-step launch leaves the window alone)
+    int step_observed(int n0, int count, double weight, int window, hipStream_t s) override {
+        if (window < 1) return fail(FDTD_ERR_ARG, "step_observed: a window must have at least one step");
+        if (count < 0) return fail(FDTD_ERR_ARG, "step_observed: negative step count");
+        int rc;
+        if (!obs_acc && (rc = dalloc((void**)&obs_acc, fsize * sizeof(T)))) return rc;
+        if (!obs_snap && (rc = dalloc((void**)&obs_snap, fsize * sizeof(T)))) return rc;
+        const bool pairs = pair_wanted();
+        for (int n = n0; n < n0 + count;) {
+            const bool two = pairs && n + 1 < n0 + count;
+            const int last = two ? n + 1 : n;
+            if (two) {
+                const bool done1 = (n + 1) % window == 0;
+                pair_acc_w = (T)weight;
+                pair_acc_flags = (n % window == 0 ? 1 : 0) | ((n + 1) % window == 0 ? 2 : 0) | (done1 ? 4 : 0);
+                rc = step_pair(n, s);
+                pair_acc_flags = -1;
+                if (rc) return rc;
+                if (done1) obs_have_window = true;
+            } else {
+                if ((rc = step(n, 1, s)) || (rc = observe_accumulate(weight, n % window == 0, s))) return rc;
+            }
+            if ((last + 1) % window == 0) {          // the window is complete as it stands
+                FDTD_HIP(hipMemcpyAsync(obs_snap, obs_acc, fsize * sizeof(T), hipMemcpyDeviceToDevice, s));
+                obs_have_window = true;
+            }
+            n = last + 1;
+        }
         return FDTD_OK;
+    }
+    int observe_rms_window(double* host, size_t n) override {
+        if (n != (size_t)d.Nx * d.Nz || !host) return fail(FDTD_ERR_ARG, "observe_rms_window: expected %zu values", (size_t)d.Nx * d.Nz);
+        if (!obs_have_window) return fail(FDTD_ERR_STATE, "observe_rms_window: no window has been completed yet");
+        return download_window(obs_snap, host);
     }
 
     struct Map { int n0 = 0, n1 = 0; T* dev = nullptr; T* dev2 = nullptr; size_t dev_elems = 0; int kind = -1, s = 0; bool mag = false; int fam = -1, slot = -1; };
@@ -540,6 +585,8 @@ struct Engine2 : fdtd2d_engine {
         a.dt = (T)d.dt; a.dtd[0] = (T)(d.dt / d.dx); a.dtd[1] = (T)(d.dt / d.dz); a.mu0 = (T)d.mu0; a.eps0 = (T)d.eps0;
         a.jy = s1 ? a.dt * Jy[n] : (T)0;
         a.jy2 = s2 ? a.dt * Jy[n + 1] : (T)0;
+        const bool acc = pair_acc_flags >= 0;
+        a.acc = acc ? obs_acc : nullptr; a.acc_snap = acc ? obs_snap : nullptr; a.acc_w = pair_acc_w; a.acc_flags = acc ? pair_acc_flags : 0;
         a.chunk = chunk_p; a.ntx = ntx3;
         a.nbz = (nz1 + chunk_p - 1) / chunk_p;
         a.remap = remap_set ? remap : 0;
@@ -557,12 +604,14 @@ struct Engine2 : fdtd2d_engine {
             if (beside) { FDTD_HIP(hipEventRecord(lz_fork, s)); FDTD_HIP(hipStreamWaitEvent(ls, lz_fork, 0)); }
             K2P<T> b = a;
             b.tiles = tiles3_d + n_plain3; b.n_tiles = n_lz3; b.nbx = (n_lz3 + kPairTiles2D - 1) / kPairTiles2D;
-            hipLaunchKernelGGL((k2_pair<T, PV, true>), dim3((unsigned)b.nbx * b.nbz), dim3(kLanes * kPairTiles2D), 0, ls, b);
+            if (acc) hipLaunchKernelGGL((k2_pair<T, PV, true, true>), dim3((unsigned)b.nbx * b.nbz), dim3(kLanes * kPairTiles2D), 0, ls, b);
+            else hipLaunchKernelGGL((k2_pair<T, PV, true>), dim3((unsigned)b.nbx * b.nbz), dim3(kLanes * kPairTiles2D), 0, ls, b);
             if (beside) FDTD_HIP(hipEventRecord(lz_join, ls));
         }
         if (n_plain3) {
             a.tiles = tiles3_d; a.n_tiles = n_plain3; a.nbx = (n_plain3 + kPairTiles2D - 1) / kPairTiles2D;
-            hipLaunchKernelGGL((k2_pair<T, PV, false>), dim3((unsigned)a.nbx * a.nbz), dim3(kLanes * kPairTiles2D), 0, s, a);
+            if (acc) hipLaunchKernelGGL((k2_pair<T, PV, false, true>), dim3((unsigned)a.nbx * a.nbz), dim3(kLanes * kPairTiles2D), 0, s, a);
+            else hipLaunchKernelGGL((k2_pair<T, PV, false>), dim3((unsigned)a.nbx * a.nbz), dim3(kLanes * kPairTiles2D), 0, s, a);
         }
         if (beside) FDTD_HIP(hipStreamWaitEvent(s, lz_join, 0));
         timer.end(s);
@@ -660,6 +709,10 @@ int fdtd2d_sumsq(fdtd2d_handle h, int id, double* out, void* stream) {
 size_t fdtd2d_device_bytes(fdtd2d_handle h) { return h ? h->device_bytes() : 0; }
 int fdtd2d_observe_accumulate(fdtd2d_handle h, double weight, int reset, void* stream) { return entry(h, [&] { return h->observe_accumulate(weight, reset, (hipStream_t)stream); }); }
 int fdtd2d_observe_rms(fdtd2d_handle h, double* host, size_t n) { return entry(h, [&] { return h->observe_rms(host, n); }); }
+int fdtd2d_step_observed(fdtd2d_handle h, int n0, int count, double weight, int window, void* stream) {
+    return entry(h, [&] { return h->step_observed(n0, count, weight, window, (hipStream_t)stream); });
+}
+int fdtd2d_observe_rms_window(fdtd2d_handle h, double* host, size_t n) { return entry(h, [&] { return h->observe_rms_window(host, n); }); }
 int fdtd2d_probe_add(fdtd2d_handle h, int id, int i, int k) { return entry(h, [&] { return h->probe_add(id, i, k); }); }
 int fdtd2d_probe_record(fdtd2d_handle h, void* stream) { return entry(h, [&] { return h->probe_record((hipStream_t)stream); }); }
 int fdtd2d_probe_read(fdtd2d_handle h, double* out, size_t cap, int* n_samples, int* n_probes) { return entry(h, [&] { return h->probe_read(out, cap, n_samples, n_probes); }); }

@@ -47,6 +47,10 @@ struct K2P {
     int chunk, ntx, nbx, nbz, remap;
     const unsigned char* disp;                     // [nz1][ntx]: any Lorentz coefficient non-zero in the 64 packs of that wave
     const int* tiles; int n_tiles;                 // the x tiles this launch covers
+    // ACC: the running RMS window of Ey rides along (FDTD2D::run, FDTD2D.cpp:515-522: acc(i,k) (+)= Ey^2 * weight after
+    // every step); flags: 1 = the first step opens a new window, 2 = the second does, 4 = keep the window as the first
+    // step leaves it in `acc_snap`
+    T* acc; T* acc_snap; T acc_w; int acc_flags;
 };
 template <typename T> using ArgBlock2P = const FDTD_AS(4) K2P<T>*;
 
@@ -57,7 +61,7 @@ template <int V> constexpr int pair2d_halo_lanes() { return V >= 2 ? 1 : 2; }
 
 // LZ = false: for x tiles none of whose row segments holds a Lorentz cell -- the kernel without the recursion, its
 // loads and its registers (more waves per SIMD); the tiles that do hold such cells go through LZ = true in a launch of their own.
-template <typename T, int V, bool LZ>
+template <typename T, int V, bool LZ, bool ACC = false>
 __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a) {
     constexpr int HL = pair2d_halo_lanes<V>();
     constexpr int OWN = (kLanes - 2 * HL) * V;           // columns a wave owns (tile 0 owns its first lanes as well)
@@ -161,11 +165,12 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
     auto request_flag = [&](int k) { if constexpr (LZ) pf = (k >= 0 && k < nz1) ? a.disp[(size_t)k * a.ntx + tx] : (unsigned char)0; };
     request_flag(kb - 1);
     // Dy, Bx, Bz of the row the next iteration starts with
-    P nd = zero_pack<T, V>(), nbx = nd, nbz = nd;
+    P nd = zero_pack<T, V>(), nbx = nd, nbz = nd, nacc = nd, acc1_km = nd;
     auto request_row = [&](int k) {
         if (INNER || (k >= 0 && k < nz1)) {
             const size_t q = (size_t)k * px + c0;
             nd = ldg<T, V>(ap->Dy + q, lo); nbx = ldg<T, V>(ap->Bx + q, lo); nbz = ldg<T, V>(ap->Bz + q, lo);
+            if constexpr (ACC) { if (k >= kb && k < ke && !(a.acc_flags & 1)) nacc = ldg<T, V>(ap->acc + q, lo); }
         }
     };
     request_row(kb - 1);
@@ -175,7 +180,7 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
         const bool fl_k = LZ && __builtin_amdgcn_readfirstlane((int)pf) != 0;
         const size_t ro = (size_t)(INNER ? k : (k < 0 ? 0 : (k < nz1 ? k : nz1 - 1))) * px + c0;        // uniform offset of row k's segment (clamped: rows outside are not touched)
         const int km = k - 1, km2 = k - 2;
-        const P cur_d = nd, cur_bx = nbx, cur_bz = nbz;
+        const P cur_d = nd, cur_bx = nbx, cur_bz = nbz, cur_acc = nacc;
         if (k < ke + 1) { request_row(k + 1); request_flag(k + 1); }
 
         // ---------------------------------------------------------------- A: row k, first step: H0, Dy1, Ey1
@@ -211,6 +216,15 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
                     e1 = divide<T, V>(d1, a.eps0);
                 }
                 if (!valid) e1 = zero_pack<T, V>();
+            }
+        }
+        P acc1 = zero_pack<T, V>();
+        if constexpr (ACC) {
+            if (k >= kb && k < ke && k < Nz) {            // the window after the first step, own rows
+                if (!(a.acc_flags & 1)) acc1 = cur_acc;
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc1.v[e] = acc1.v[e] + e1.v[e] * e1.v[e] * a.acc_w;
+                if ((a.acc_flags & 4) && own_lane) stg<T, V>(ap->acc_snap + ro, lo, acc1);
             }
         }
 
@@ -285,6 +299,14 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
                         e2 = divide<T, V>(d2, a.eps0);
                     }
                     if (!valid) e2 = zero_pack<T, V>();
+                    if constexpr (ACC) {
+                        if (st) {                          // the window after the second step
+                            P a2 = (a.acc_flags & 2) ? zero_pack<T, V>() : acc1_km;
+#pragma unroll
+                            for (int e = 0; e < V; ++e) a2.v[e] = a2.v[e] + e2.v[e] * e2.v[e] * a.acc_w;
+                            stg<T, V>(ap->acc + q, lo, a2);
+                        }
+                    }
                 }
             }
         }
@@ -327,6 +349,7 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
         h1x_km2 = h1x; h1z_km2 = h1z; e2_km2 = e2; b1x_km2 = b1x; b1z_km2 = b1z; sh1x_km2 = sh1x; sh1z_km2 = sh1z; pmz_km2 = pmz; pmx_km2 = pmx;
         e1_km = e1; d1_km = d1; bx0_km = bx0; bz0_km = bz0; s1e_km = s1e; pez_km = pez; pex_km = pex;
         fl_km2 = fl_km; fl_km = fl_k;
+        acc1_km = acc1;
     }
     };
     if (inner_wave) run(std::true_type{}); else run(std::false_type{});

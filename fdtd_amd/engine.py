@@ -499,6 +499,17 @@ class Engine2D(_Common):
     def step(self, n0: int, count: int = 1, stream=None) -> None:
         _check(lib().fdtd2d_step(self.h, C.c_int(n0), C.c_int(count), _stream_handle(stream)), "fdtd2d_step")
 
+    def step_observed(self, n0: int, count: int, weight: float, window: int, stream=None) -> None:
+        """`count` steps with the RMS window of Ey advanced after each (fdtd2d_step_observed)."""
+        _check(lib().fdtd2d_step_observed(self.h, C.c_int(n0), C.c_int(count), C.c_double(weight), C.c_int(window), _stream_handle(stream)),
+               "fdtd2d_step_observed")
+
+    def observe_rms_window(self) -> np.ndarray:
+        """sqrt of the last completed window, [Nx][Nz] with k fastest."""
+        out = np.zeros(self.Nx * self.Nz)
+        _check(lib().fdtd2d_observe_rms_window(self.h, out.ctypes.data_as(_dp), C.c_size_t(out.size)), "fdtd2d_observe_rms_window")
+        return out
+
 
 class _DeviceSpan:
     """Exposes a raw device address range through __cuda_array_interface__ so that torch can wrap it

@@ -452,13 +452,25 @@ int fdtd2d_destroy(fdtd2d_handle h);
 size_t fdtd2d_array_size(fdtd2d_handle h, int id);
 int fdtd2d_set_array(fdtd2d_handle h, int id, const double* host, size_t n);
 int fdtd2d_get_array(fdtd2d_handle h, int id, double* host, size_t n);
-/* Advance `count` steps n0.. (FDTD2D::stepOnce).  Asynchronous on `stream`. */
+/* Advance `count` steps n0.. (FDTD2D::stepOnce).  Asynchronous on `stream`.  A FUSED engine without probes takes its
+ * steps two per launch (one pass over Dy, Bx, Bz per two steps; an odd step at the end is a launch of the one-step
+ * kernel) on grids of at least 4 Mi cells; the environment variable FDTD2D_PAIR=0/1 decides otherwise.  The result is
+ * the same bit for bit either way.  With a probe registered every step is a launch of its own: a probe is sampled
+ * after every step. */
 int fdtd2d_step(fdtd2d_handle h, int n0, int count, void* stream);
 int fdtd2d_sumsq(fdtd2d_handle h, int id, double* out, void* stream);
 /* RMS window of Ey on the device (FDTD2D::run, FDTD2D.cpp:515-522): acc(i,k) (+)= Ey^2 * weight for
  * i < Nx, k < Nz; rms writes sqrt(acc) as [Nx][Nz] with k fastest, the order of the CSV writer. */
 int fdtd2d_observe_accumulate(fdtd2d_handle h, double weight, int reset, void* stream);
 int fdtd2d_observe_rms(fdtd2d_handle h, double* host, size_t n);
+/* The body of the reference's time loop for a run of steps (FDTD2D::run, FDTD2D.cpp:510-522): for n = n0 .. n0+count-1
+ * step, then acc (+)= Ey^2 * weight with a new window opened when n % window == 0; a window that completes
+ * ((n + 1) % window == 0) is kept until the next one completes and read with fdtd2d_observe_rms_window, the one being
+ * accumulated with fdtd2d_observe_rms.  Steps that go two per launch (see fdtd2d_step) advance the window inside the
+ * launch, from the Ey values the kernel has in registers.  Equal, bit for bit, to fdtd2d_step(n, 1) followed by
+ * fdtd2d_observe_accumulate(weight, n % window == 0) for every step. */
+int fdtd2d_step_observed(fdtd2d_handle h, int n0, int count, double weight, int window, void* stream);
+int fdtd2d_observe_rms_window(fdtd2d_handle h, double* host, size_t n);
 size_t fdtd2d_device_bytes(fdtd2d_handle h);
 /* Probe time series, as in 3-D: cells (i, k) of the field arrays (ids 0..20) or C1..C3; fdtd2d_step
  * records one sample per step. */
@@ -466,7 +478,7 @@ int fdtd2d_probe_add(fdtd2d_handle h, int id, int i, int k);
 int fdtd2d_probe_record(fdtd2d_handle h, void* stream);
 int fdtd2d_probe_read(fdtd2d_handle h, double* out, size_t cap, int* n_samples, int* n_probes);
 int fdtd2d_probe_reset(fdtd2d_handle h, int drop_probes);
-/* Kernel timing as in 3-D; kinds: 0 = E part, 1 = H part, 2 = fused step. */
+/* Kernel timing as in 3-D; kinds: 0 = E part, 1 = H part, 2 = fused step, 3 = two steps per launch. */
 int fdtd2d_kernel_timing(fdtd2d_handle h, int enable);
 int fdtd2d_kernel_time(fdtd2d_handle h, int kind, int* launches, double* total_ms);
 

@@ -177,6 +177,89 @@ def test_fused2d_observables_equal_twin():
     util.assert_equal_arrays(eng.observe_rms(), tw.observe_rms(), "2-D fused RMS window")
 
 
+@pytest.mark.parametrize("prec", [32, 64])
+@pytest.mark.parametrize("window", [1, 2, 5])
+def test_window_inside_two_step_launches_2d(prec, window):
+    """fdtd2d_step_observed on the reference's slab problem: calls of odd and even length starting at odd and even steps;
+    the window being accumulated and the last completed one equal stepping and accumulating one step at a time on the
+    twin, bit for bit (with two steps per launch the window is advanced by the step kernel itself)."""
+    meta, ins, _, _ = util.load_fixture("g4_2d_slab")
+    eng = fdtd_amd.Engine2D(meta["Nx"], meta["Nz"], meta["npml"], meta["dx"], meta["dz"], meta["dt"], meta["mu0"], meta["eps0"],
+                            meta["i_Jy"], meta["k_Jy"], meta["steps"], precision=prec, mode=MODE2D_FUSED)
+    tw = util.twin2d_from_meta(meta, prec)
+    util.feed(eng, ins)
+    util.feed(tw, ins)
+    with pytest.raises(fdtd_amd.engine.EngineError, match="no window has been completed"):
+        eng.observe_rms_window()
+    n, kept = 0, None
+    for count in (1, 6, 7, 2, 9):
+        eng.step_observed(n, count, 0.05, window)
+        for m in range(n, n + count):
+            tw.step(m, 1)
+            tw.observe_accumulate(0.05, m % window == 0)
+            if (m + 1) % window == 0:
+                kept = tw.observe_rms().copy()
+        n += count
+        util.assert_equal_arrays(eng.observe_rms(), tw.observe_rms(), f"fp{prec} window {window}: accumulating, after step {n - 1}")
+        if kept is not None:
+            util.assert_equal_arrays(eng.observe_rms_window(), kept, f"fp{prec} window {window}: completed, after step {n - 1}")
+    assert kept is not None and kept.max() > 0
+    mask = np.asarray(ins[po.D2_C1]).reshape(meta["Nx"], meta["Nz"]) != 0
+    compare_2d(eng, tw.get, meta["Nx"], meta["Nz"], meta["npml"], mask, f"fp{prec} after {n} observed steps")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_window_random_configurations_2d(seed):
+    """Random 2-D grids (one to several x tiles), CPML layers, dispersive cells, window and run lengths."""
+    rng = np.random.default_rng(7000 + seed)
+    Nx = int(rng.choice([rng.integers(8, 60), rng.integers(120, 140), rng.integers(245, 262), rng.integers(300, 500)]))
+    Nz = int(rng.integers(6, 50))
+    npml = [int(rng.integers(0, 6)) if rng.random() < 0.7 else 0 for _ in range(4)]
+    while npml[0] + npml[1] >= max(Nx - 9, 1):
+        npml[0], npml[1] = npml[0] // 2, npml[1] // 2
+    while npml[2] + npml[3] >= Nz - 1:
+        npml[2], npml[3] = npml[2] // 2, npml[3] // 2
+    prec = int(rng.choice([32, 64]))
+    window = int(rng.choice([1, 2, 3, 4, 7]))
+    counts = [int(rng.integers(1, 9)) for _ in range(3)]
+    steps = sum(counts)
+    K = po.consts()
+    dx, dz = 5e-8, 6e-8
+    dt = dx / (2 * K["c0"])
+    iJ, kJ = int(rng.integers(0, Nx)), int(rng.integers(0, Nz + 1))
+    eng = fdtd_amd.Engine2D(Nx, Nz, npml, dx, dz, dt, K["mu0"], K["eps0"], iJ, kJ, steps, precision=prec, mode=MODE2D_FUSED)
+    tw = po.Twin2D(prec, Nx, Nz, npml, dx, dz, dt, K["mu0"], K["eps0"], iJ, kJ, steps)
+    mask = rng.random((Nx, Nz)) < (0.02 if seed % 2 else 0.0)
+    Cs = [np.where(mask, 0.02 * rng.random((Nx, Nz)), 0.0), np.where(mask, -1.9 + 0.01 * rng.random((Nx, Nz)), 0.0),
+          np.where(mask, 1 + 0.01 * rng.random((Nx, Nz)), 0.0)]
+    jy = rng.standard_normal(steps) * 1e3
+    dd = (dx, dz)
+    for be in (eng, tw):
+        for a in range(2):
+            for s in range(2):
+                if npml[a * 2 + s]:
+                    tabs = po.cpml_face(npml[a * 2 + s], s, dd[a], dz, dt)
+                    for k in range(6):
+                        be.set(po.D2_TAB + (a * 2 + s) * 6 + k, tabs[k])
+        for q in range(3):
+            be.set(po.D2_C1 + q, Cs[q])
+        be.set(po.D2_JY, jy)
+    what = f"seed {seed}: {Nx}x{Nz} npml={npml} fp{prec} window {window} counts {counts}"
+    n, kept = 0, None
+    for count in counts:
+        eng.step_observed(n, count, 0.3, window)
+        for m in range(n, n + count):
+            tw.step(m, 1)
+            tw.observe_accumulate(0.3, m % window == 0)
+            if (m + 1) % window == 0:
+                kept = tw.observe_rms().copy()
+        n += count
+        util.assert_equal_arrays(eng.observe_rms(), tw.observe_rms(), f"{what}: accumulating after step {n - 1}")
+        if kept is not None:
+            util.assert_equal_arrays(eng.observe_rms_window(), kept, f"{what}: completed window after step {n - 1}")
+    compare_2d(eng, tw.get, Nx, Nz, npml, mask, what)
+
+
 def test_tiny_grids_2d_equal_twin():
     """2-D grids of 2, 3, 5 and 9 cells per axis, with and without a one-layer CPML, both step paths, both
     precisions, with and without scattered dispersive cells: 256 problems == the twin."""

@@ -152,6 +152,11 @@ def test_fdtd2d_driver_writes_the_reference_files(tmp_path):
     _run("fdtd2d", dict(FDTD2D_NX=meta["Nx"], FDTD2D_NZ=meta["Nz"], FDTD2D_NPML=meta["npml"][0], FDTD2D_STEPS=meta["steps"],
                         FDTD2D_IJY=meta["i_Jy"], FDTD2D_KJY=meta["k_Jy"], FDTD2D_PRECISION=64, FDTD2D_FUSED=0), str(tmp_path))
     _compare_dir(str(tmp_path / "output_2d"), fx)
+    # two steps per launch with the RMS window advanced inside the launches; one engine call per step
+    for extra in (dict(FDTD2D_PAIR=1), dict(FDTD2D_PAIR=1, FDTD_Z_CHUNK2D_PAIR=3), dict(FDTD2D_STEP_BY_STEP=1)):
+        _run("fdtd2d", dict(FDTD2D_NX=meta["Nx"], FDTD2D_NZ=meta["Nz"], FDTD2D_NPML=meta["npml"][0], FDTD2D_STEPS=meta["steps"],
+                            FDTD2D_IJY=meta["i_Jy"], FDTD2D_KJY=meta["k_Jy"], FDTD2D_PRECISION=64, **extra), str(tmp_path))
+        _compare_dir(str(tmp_path / "output_2d"), fx)
     assert "dims.txt" in names and "eymag_t00080.csv" in names and "ey_t00081.csv" in names
 
 
