@@ -1,4 +1,4 @@
-"""The suite's randomized parity tests (fused, two steps per launch, the RMS window inside them, slab groups in both choreographies, two-kernel, 3-D whole grids and slab partitions, 2-D)
+"""The suite's randomized parity tests (fused, two steps per launch, the RMS window inside them, slab groups in both choreographies, two-kernel, 3-D whole grids and slab partitions, 2-D with one and with two steps per launch)
 over a range of further seeds:  python tools/stress_parity.py LO HI   (needs the GPU; ~8 seeds per second)."""
 import sys, time, traceback
 import os
@@ -16,6 +16,18 @@ def group_two_step(seed):
 
 
 
+def fused2d_two_step(seed):
+    """The random 2-D problems with two steps per launch (rows per wave drawn from the seed), then the RMS window inside them."""
+    os.environ["FDTD2D_PAIR"] = "1"
+    os.environ["FDTD_Z_CHUNK2D_PAIR"] = str((1, 2, 3, 5, 8, 32)[seed % 6])
+    try:
+        t2.test_fused2d_random_configurations_equal_twin(seed)
+        t2.test_window_random_configurations_2d(seed)
+    finally:
+        os.environ.pop("FDTD2D_PAIR", None)
+        os.environ.pop("FDTD_Z_CHUNK2D_PAIR", None)
+
+
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 t0 = time.time()
@@ -29,7 +41,8 @@ for seed in range(lo, hi):
         except Exception as e:
             bad += 1
             print(f"FAIL {name} seed {seed}: {str(e)[:300]}", flush=True)
-    for name, fn in (("fused2d", getattr(t2, "test_fused2d_random_configurations_equal_twin", None)), ("2d", tp.test_random_configurations_2d_equal_twin)):
+    for name, fn in (("fused2d", getattr(t2, "test_fused2d_random_configurations_equal_twin", None)), ("fused2d two-step", fused2d_two_step),
+                     ("2d", tp.test_random_configurations_2d_equal_twin)):
         if fn is None: continue
         try:
             fn(seed)
