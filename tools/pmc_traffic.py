@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--kernels", default="k3_,k2_", help="comma-separated substrings of the kernel names to keep")
     ap.add_argument("--workload", default="")
+    ap.add_argument("--variants", action="store_true", help="keep the template arguments in the kernel names (one record per instantiation)")
     ap.add_argument("prog", nargs=argparse.REMAINDER)
     args = ap.parse_args()
     prog = [p for p in args.prog if p != "--"]
@@ -61,7 +62,7 @@ def main():
     for name in sorted(set(fetch) | set(write)):
         if not any(k in name for k in keep):
             continue
-        short = name.split("<")[0].split("(")[0].replace("void ", "").replace("fdtd::", "").strip()
+        short = (name.split("(")[0] if args.variants else name.split("<")[0].split("(")[0]).replace("void ", "").replace("fdtd::", "").strip()
         f, nf = fetch.get(name, [0.0, 0])
         w, nw = write.get(name, [0.0, 0])
         rec = per.setdefault(short, {"launches": 0, "read_bytes": 0.0, "write_bytes": 0.0})

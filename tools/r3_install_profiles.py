@@ -45,4 +45,12 @@ for name in ("r3_traffic_1024_pair.json", "r3_traffic_1024_fused.json"):
     shutil.copy(os.path.join(O, name), os.path.join(P, name))
 shutil.copy(os.path.join(O, "r3_pmc_clock_final.md"), os.path.join(P, "r3_pmc_clock_cold_vs_noise_final.md"))
 shutil.copy(os.path.join(O, "r3_group_two_slabs_one_gpu.log"), os.path.join(P, "r3_group_two_slabs_one_gpu.md"))
+for name in ("r3_traffic_8192_2d_pair.json", "r3_traffic_8192_2d_fused.json", "r3_bench2d_observed.json"):
+    if os.path.exists(os.path.join(O, name)):
+        shutil.copy(os.path.join(O, name), os.path.join(P, name))
+f2 = newest("r3_prof_2d/**/*_kernel_stats.csv")
+if f2:
+    shutil.copy(f2, os.path.join(P, "r3_kernel_stats_2d_8192_pair.csv"))
+    line = [l for l in open(os.path.join(O, "r3_bench_2d_8192_under_rocprof.json")) if l.startswith("{")][-1]
+    open(os.path.join(P, "r3_bench_2d_8192_under_rocprof.json"), "w").write(json.dumps(json.loads(line), indent=1) + "\n")
 print("installed")
