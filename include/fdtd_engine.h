@@ -454,7 +454,8 @@ int fdtd2d_set_array(fdtd2d_handle h, int id, const double* host, size_t n);
 int fdtd2d_get_array(fdtd2d_handle h, int id, double* host, size_t n);
 /* Advance `count` steps n0.. (FDTD2D::stepOnce).  Asynchronous on `stream`.  A FUSED engine without probes takes its
  * steps two per launch (one pass over Dy, Bx, Bz per two steps; an odd step at the end is a launch of the one-step
- * kernel) on grids of at least 4 Mi cells; the environment variable FDTD2D_PAIR=0/1 decides otherwise.  The result is
+ * kernel) on grids of at least 4 Mi cells; the environment variable FDTD2D_PAIR=0/1 decides otherwise, and
+ * FDTD_Z_CHUNK2D_PAIR sets the rows a wave of that kernel owns (default 8; read when the engine is created).  The result is
  * the same bit for bit either way.  With a probe registered every step is a launch of its own: a probe is sampled
  * after every step. */
 int fdtd2d_step(fdtd2d_handle h, int n0, int count, void* stream);
