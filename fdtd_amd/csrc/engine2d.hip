@@ -528,13 +528,11 @@ struct Engine2 : fdtd2d_engine {
     int pair_prepare() {
         int rc;
         if (!pair_allocated) {
-            const size_t fb = (fsize + px) * sizeof(T);
             for (int sd = 0; sd < 2; ++sd) {
                 if (np[1][sd] && (rc = dalloc((void**)&pm_z2[sd], ((size_t)np[1][sd] * px + px) * sizeof(T)))) return rc;
                 if (np[0][sd] && (rc = dalloc((void**)&pm_x2[sd], ((size_t)nz1 * (sd ? xwp : xwn) + px) * sizeof(T)))) return rc;
             }
             pair_allocated = true;
-            (void)fb;
         }
         if (any_disp && !Fx[0]) {
             const size_t fb = (fsize + px) * sizeof(T);
