@@ -208,6 +208,28 @@ def test_window_inside_two_step_launches_2d(prec, window):
     compare_2d(eng, tw.get, meta["Nx"], meta["Nz"], meta["npml"], mask, f"fp{prec} after {n} observed steps")
 
 
+def test_observed_steps_two_kernel_mode_2d():
+    """Engines that keep every array of the reference (two kernels per step) take the same call: step, then the observe
+    kernel, and the completed window is kept the same way."""
+    meta, ins, _, _ = util.load_fixture("g4_2d_slab")
+    eng = fdtd_amd.Engine2D(meta["Nx"], meta["Nz"], meta["npml"], meta["dx"], meta["dz"], meta["dt"], meta["mu0"], meta["eps0"],
+                            meta["i_Jy"], meta["k_Jy"], meta["steps"], precision=64, mode=0)
+    tw = util.twin2d_from_meta(meta, 64)
+    util.feed(eng, ins)
+    util.feed(tw, ins)
+    eng.step_observed(0, 11, 0.1, 4)
+    kept = None
+    for n in range(11):
+        tw.step(n, 1)
+        tw.observe_accumulate(0.1, n % 4 == 0)
+        if (n + 1) % 4 == 0:
+            kept = tw.observe_rms().copy()
+    util.assert_equal_arrays(eng.observe_rms(), tw.observe_rms(), "window being accumulated")
+    util.assert_equal_arrays(eng.observe_rms_window(), kept, "last completed window")
+    with pytest.raises(fdtd_amd.engine.EngineError, match="at least one step"):
+        eng.step_observed(11, 2, 0.1, 0)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_window_random_configurations_2d(seed):
     """Random 2-D grids (one to several x tiles), CPML layers, dispersive cells, window and run lengths."""
