@@ -38,7 +38,8 @@ public:
 
     void run();
     const Sim2DConfig& config() const { return m_cfg; }
-    double seconds_in_steps() const { return m_step_seconds; }
+    double seconds_in_steps() const { return m_step_seconds; }            // time loop incl. downloads and file output
+    double seconds_on_device() const { return m_device_seconds; }         // stepping + RMS window on the device only
 
 private:
     void build();
@@ -48,5 +49,5 @@ private:
     fdtd2d_engine* m_engine = nullptr;
     std::unique_ptr<FieldWriter2D> m_out;
     std::vector<double> m_ey, m_center;
-    double m_step_seconds = 0.0;
+    double m_step_seconds = 0.0, m_device_seconds = 0.0;
 };

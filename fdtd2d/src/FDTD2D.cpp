@@ -149,6 +149,8 @@ void FDTD2D::run() {
         const int next_done = (n + half_period) / half_period * half_period - 1;                 // first step >= n that completes a window
         const int last = c.step_by_step ? n : std::min(std::min(next_dump, next_done + (half_period > 1 ? 1 : 0)), c.steps - 1);
         must(fdtd2d_step_observed(m_engine, n, last - n + 1, weight, half_period, nullptr), "step");
+        must(fdtd2d_sync(m_engine, nullptr), "sync");
+        m_device_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (next_done <= last) {
             must(fdtd2d_observe_rms_window(m_engine, m_center.data(), m_center.size()), "RMS download");
             if (m_out) m_out->write_csv(numbered("eymag_t", next_done + 1), m_center, c.Nx, c.Nz, c.dx, c.dz);

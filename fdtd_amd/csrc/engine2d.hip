@@ -711,6 +711,9 @@ int fdtd2d_step_observed(fdtd2d_handle h, int n0, int count, double weight, int 
     return entry(h, [&] { return h->step_observed(n0, count, weight, window, (hipStream_t)stream); });
 }
 int fdtd2d_observe_rms_window(fdtd2d_handle h, double* host, size_t n) { return entry(h, [&] { return h->observe_rms_window(host, n); }); }
+int fdtd2d_sync(fdtd2d_handle h, void* stream) {
+    return entry(h, [&] { FDTD_HIP(hipStreamSynchronize((hipStream_t)stream)); return (int)FDTD_OK; });
+}
 int fdtd2d_probe_add(fdtd2d_handle h, int id, int i, int k) { return entry(h, [&] { return h->probe_add(id, i, k); }); }
 int fdtd2d_probe_record(fdtd2d_handle h, void* stream) { return entry(h, [&] { return h->probe_record((hipStream_t)stream); }); }
 int fdtd2d_probe_read(fdtd2d_handle h, double* out, size_t cap, int* n_samples, int* n_probes) { return entry(h, [&] { return h->probe_read(out, cap, n_samples, n_probes); }); }

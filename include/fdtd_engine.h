@@ -472,6 +472,8 @@ int fdtd2d_observe_rms(fdtd2d_handle h, double* host, size_t n);
  * fdtd2d_observe_accumulate(weight, n % window == 0) for every step. */
 int fdtd2d_step_observed(fdtd2d_handle h, int n0, int count, double weight, int window, void* stream);
 int fdtd2d_observe_rms_window(fdtd2d_handle h, double* host, size_t n);
+/* Waits for everything queued on `stream` (stepping calls return once their work is queued; downloads wait by themselves). */
+int fdtd2d_sync(fdtd2d_handle h, void* stream);
 size_t fdtd2d_device_bytes(fdtd2d_handle h);
 /* Probe time series, as in 3-D: cells (i, k) of the field arrays (ids 0..20) or C1..C3; fdtd2d_step
  * records one sample per step. */
