@@ -39,7 +39,7 @@ def kernel_source_digest() -> str:
     (HBM traffic from a profiler pass) is not quoted next to timings of another."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("common.hpp", "kernels3d.hpp", "kernels3d_fused.hpp", "kernels3d_pair.hpp", "kernels2d.hpp", "kernels2d_fused.hpp"):
+    for name in ("common.hpp", "kernels3d.hpp", "kernels3d_fused.hpp", "kernels3d_pair.hpp", "kernels2d.hpp", "kernels2d_fused.hpp", "kernels2d_pair.hpp"):
         with open(os.path.join(_HERE, "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()
