@@ -7,6 +7,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <utility>
 
 using namespace fdtd;
 
@@ -51,7 +53,55 @@ __global__ void k2_observe(const T* ey, T* acc, int Nx, int Nz, int px, T weight
         acc[t] = old + e * e * weight;
     }
 }
+
+// Every fp32 bit pattern of the class of `d` through the short division and through the IEEE one; counts disagreements.
+__global__ void k_const_div_verify(ConstDiv<float> d, unsigned long long* bad) {
+    unsigned long long mine = 0;
+    const unsigned long long total = 1ull << 32;
+    for (unsigned long long u = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((unsigned)u);
+        if (!const_div_in_class(x, d)) continue;
+        const float q = const_div_short(x, d), want = x / d.c;
+        if (__float_as_uint(q) != __float_as_uint(want)) ++mine;
+    }
+    if (mine) atomicAdd(bad, mine);
+}
 }  // namespace fdtd
+
+namespace {
+// The constant's reciprocal and class bounds, and -- fp32 only -- whether the short division has been proven equal to the
+// IEEE one for every numerator of the class on the current device (cached per constant; FDTD_CONST_DIV=0 turns it off).
+template <typename T> int make_const_div(double c, fdtd::ConstDiv<T>& out);
+template <> int make_const_div<double>(double c, fdtd::ConstDiv<double>& out) { out = {c, 1.0 / c, 0.0, 0.0, 0}; return FDTD_OK; }
+template <> int make_const_div<float>(double cd, fdtd::ConstDiv<float>& out) {
+    const float c = (float)cd;
+    out = {c, 1.0f / c, 0.0f, 0.0f, 0};
+    static std::vector<std::pair<unsigned, int>> cache;       // (bits of c, proven)
+    static std::mutex cache_lock;
+    std::lock_guard<std::mutex> guard(cache_lock);
+    const char* env = getenv("FDTD_CONST_DIV");
+    if ((env && atoi(env) == 0) || !(c > 0.0f) || !std::isfinite(c) || !std::isfinite(out.r)) return FDTD_OK;
+    // the class: numerator, quotient and remainder well inside the normal range
+    out.lo = 0x1p-80f * std::max(1.0f, c);
+    out.hi = 0x1p+80f * std::min(1.0f, c);
+    if (!(out.lo < out.hi)) return FDTD_OK;
+    unsigned bits;
+    std::memcpy(&bits, &c, 4);
+    for (const auto& e : cache) if (e.first == bits) { out.fast = e.second; return FDTD_OK; }
+    unsigned long long* bad_d = nullptr;
+    unsigned long long bad = 1;
+    FDTD_HIP(hipMalloc((void**)&bad_d, sizeof bad));
+    FDTD_HIP(hipMemset(bad_d, 0, sizeof bad));
+    out.fast = 1;                                               // (the verifier evaluates the class with the bounds above)
+    hipLaunchKernelGGL(fdtd::k_const_div_verify, dim3(256 * 64), dim3(256), 0, 0, out, bad_d);
+    FDTD_HIP(hipGetLastError());
+    FDTD_HIP(hipMemcpy(&bad, bad_d, sizeof bad, hipMemcpyDeviceToHost));
+    FDTD_HIP(hipFree(bad_d));
+    out.fast = bad == 0 ? 1 : 0;
+    cache.emplace_back(bits, out.fast);
+    return FDTD_OK;
+}
+}  // namespace
 
 struct fdtd2d_engine {
     virtual ~fdtd2d_engine() {}
@@ -229,6 +279,7 @@ struct Engine2 : fdtd2d_engine {
             if ((rc = dalloc((void**)&disp3_d, (size_t)nz1 * ntx3 + 64))) return rc;
             if (const char* e = getenv("FDTD_Z_CHUNK2D_PAIR")) { int c = atoi(e); if (c >= 1 && c <= 65536) chunk_p = c; }
             if (const char* e = getenv("FDTD2D_PAIR")) pair_env = atoi(e) != 0 ? 1 : 0;
+            if ((rc = make_const_div<T>(d.mu0, cd_mu)) || (rc = make_const_div<T>(d.eps0, cd_eps))) return rc;
             if ((rc = dalloc((void**)&xrow2_d, (size_t)6 * px * sizeof(T)))) return rc;
             if ((rc = upload_tables())) return rc;
         }
@@ -507,6 +558,7 @@ struct Engine2 : fdtd2d_engine {
     // x tiles with and without Lorentz cells (any row): each kind gets a launch of its own kernel variant
     int* tiles3_d = nullptr;
     int n_plain3 = 0, n_lz3 = 0;
+    ConstDiv<T> cd_mu{}, cd_eps{};
     hipStream_t lz_stream = nullptr;
     hipEvent_t lz_fork = nullptr, lz_join = nullptr;
     int pair_tile_lists(const std::vector<unsigned char>& flags) {
@@ -583,6 +635,7 @@ struct Engine2 : fdtd2d_engine {
         a.dt = (T)d.dt; a.dtd[0] = (T)(d.dt / d.dx); a.dtd[1] = (T)(d.dt / d.dz); a.mu0 = (T)d.mu0; a.eps0 = (T)d.eps0;
         a.jy = s1 ? a.dt * Jy[n] : (T)0;
         a.jy2 = s2 ? a.dt * Jy[n + 1] : (T)0;
+        a.dm = cd_mu; a.de = cd_eps;
         const bool acc = pair_acc_flags >= 0;
         a.acc = acc ? obs_acc : nullptr; a.acc_snap = acc ? obs_snap : nullptr; a.acc_w = pair_acc_w; a.acc_flags = acc ? pair_acc_flags : 0;
         a.chunk = chunk_p; a.ntx = ntx3;
@@ -711,6 +764,24 @@ int fdtd2d_step_observed(fdtd2d_handle h, int n0, int count, double weight, int 
     return entry(h, [&] { return h->step_observed(n0, count, weight, window, (hipStream_t)stream); });
 }
 int fdtd2d_observe_rms_window(fdtd2d_handle h, double* host, size_t n) { return entry(h, [&] { return h->observe_rms_window(host, n); }); }
+int fdtd_const_division_proven(double c) {
+    fdtd::ConstDiv<float> d{};
+    if (make_const_div<float>(c, d) != FDTD_OK) return -1;
+    return d.fast;
+}
+// (test hook, not in the header: disagreements between the short and the IEEE division over every fp32 numerator with
+// |x| in [lo, hi] or x = +0 -- the proof above with bounds of the caller's choice; -1 on error)
+long long fdtd_const_division_mismatches(double c, double lo, double hi) {
+    fdtd::ConstDiv<float> d{(float)c, 1.0f / (float)c, (float)lo, (float)hi, 1};
+    unsigned long long* bad_d = nullptr;
+    unsigned long long bad = 0;
+    if (hipMalloc((void**)&bad_d, sizeof bad) != hipSuccess) return -1;
+    (void)hipMemset(bad_d, 0, sizeof bad);
+    hipLaunchKernelGGL(fdtd::k_const_div_verify, dim3(256 * 64), dim3(256), 0, 0, d, bad_d);
+    const bool ok = hipMemcpy(&bad, bad_d, sizeof bad, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(bad_d);
+    return ok ? (long long)bad : -1;
+}
 int fdtd2d_sync(fdtd2d_handle h, void* stream) {
     return entry(h, [&] { FDTD_HIP(hipStreamSynchronize((hipStream_t)stream)); return (int)FDTD_OK; });
 }

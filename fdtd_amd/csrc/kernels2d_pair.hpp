@@ -44,6 +44,7 @@ struct K2P {
     int xwn, xwp, xp0;
     int iJ, kJ, src_on;                            // src_on: bit 0 = the first step has a source sample, bit 1 = the second
     T jy, jy2, dt, dtd[2], mu0, eps0;
+    ConstDiv<T> dm, de;                            // division by mu0 and by eps0 (see ConstDiv)
     int chunk, ntx, nbx, nbz, remap;
     const unsigned char* disp;                     // [nz1][ntx]: any Lorentz coefficient non-zero in the 64 packs of that wave
     const int* tiles; int n_tiles;                 // the x tiles this launch covers
@@ -153,7 +154,8 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
     P hx0_km = zero_pack<T, V>();                                    // H0x(k-1)
     if (INNER || kb - 2 >= 0) {
         const size_t q = (size_t)(kb - 2) * px + c0;
-        hx0_km = field_of<T, V>(ldg<T, V>(ap->Bx + q, lo), a.mu0, flag_of(kb - 2), ap->F1[1] + q, ap->C1 + q, ap->C2 + q, ap->C3 + q, lo);
+        if constexpr (LZ) hx0_km = field_of<T, V>(ldg<T, V>(ap->Bx + q, lo), a.mu0, flag_of(kb - 2), ap->F1[1] + q, ap->C1 + q, ap->C2 + q, ap->C3 + q, lo);
+        else hx0_km = divide<T, V>(ldg<T, V>(ap->Bx + q, lo), a.dm);
         if (!valid) hx0_km = zero_pack<T, V>();
     }
     P e1_km = zero_pack<T, V>(), d1_km = e1_km, bx0_km = e1_km, bz0_km = e1_km, s1e_km = e1_km, pez_km = e1_km, pex_km = e1_km;      // row k-1 after the first step's D half
@@ -176,7 +178,7 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
     request_row(kb - 1);
 
     for (int k = kb - 1; k <= ke + 1; ++k) {
-        asm volatile("" : "+s"(ap));
+        if constexpr (LZ) asm volatile("" : "+s"(ap));
         const bool fl_k = LZ && __builtin_amdgcn_readfirstlane((int)pf) != 0;
         const size_t ro = (size_t)(INNER ? k : (k < 0 ? 0 : (k < nz1 ? k : nz1 - 1))) * px + c0;        // uniform offset of row k's segment (clamped: rows outside are not touched)
         const int km = k - 1, km2 = k - 2;
@@ -188,8 +190,13 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
         if (INNER || (k >= 0 && k < nz1)) {
             d1 = cur_d; bx0 = cur_bx; bz0 = cur_bz;
             if (!valid) { d1 = zero_pack<T, V>(); bx0 = d1; bz0 = d1; }
-            hx0 = field_of<T, V>(bx0, a.mu0, fl_k, ap->F1[1] + ro, ap->C1 + ro, ap->C2 + ro, ap->C3 + ro, lo);
-            P hz0 = field_of<T, V>(bz0, a.mu0, fl_k, ap->F1[2] + ro, ap->C1 + ro, ap->C2 + ro, ap->C3 + ro, lo);
+            P hz0;
+            if constexpr (LZ) {
+                hx0 = field_of<T, V>(bx0, a.mu0, fl_k, ap->F1[1] + ro, ap->C1 + ro, ap->C2 + ro, ap->C3 + ro, lo);
+                hz0 = field_of<T, V>(bz0, a.mu0, fl_k, ap->F1[2] + ro, ap->C1 + ro, ap->C2 + ro, ap->C3 + ro, lo);
+            } else {
+                divide2<T, V>(bx0, bz0, a.dm, hx0, hz0);
+            }
             if (!valid) { hx0 = zero_pack<T, V>(); hz0 = hx0; }
             T hz_l = lane_below(hz0.v[V - 1]);
             if (!INNER && lane == 0) hz_l = (T)0;        // tile 0: the wall; other tiles: lane 0 is a halo pack whose first column nobody uses
@@ -213,7 +220,7 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
                     for (int e = 0; e < V; ++e) lorentz<T>(d1.v[e] / a.eps0, c1.v[e], c2.v[e], c3.v[e], f1.v[e], f2.v[e], s1.v[e], s2.v[e], e1.v[e], s1e.v[e]);
                     if (own_lane && k >= kb && k < ke) { stg<T, V>(ap->FX[0] + ro, lo, e1); stg<T, V>(ap->SX[0] + ro, lo, s1e); }
                 } else {
-                    e1 = divide<T, V>(d1, a.eps0);
+                    e1 = divide<T, V>(d1, a.de);
                 }
                 if (!valid) e1 = zero_pack<T, V>();
             }
@@ -232,7 +239,7 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
         const T e1_r = lane_above(e1_km.v[0]);            // (taken with all lanes active)
         P b1x = bx0_km, b1z = bz0_km, h1x = zero_pack<T, V>(), h1z = h1x, sh1x = h1x, sh1z = h1x, pmz = h1x, pmx = h1x;
         if (k >= kb && (INNER || (km >= 0 && km < Nz))) {
-            asm volatile("" : "+s"(ap));
+            if constexpr (LZ) asm volatile("" : "+s"(ap));
             const size_t q = (size_t)km * px + c0;
             int lm;
             const int zm = INNER ? (lm = 0, (int)Z_MID) : zone_h(km, Nz, a.np[1][0], a.np[1][1], false, lm);
@@ -259,7 +266,7 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
                     stg<T, V>(ap->FX[2] + q, lo, h1z); stg<T, V>(ap->SX[2] + q, lo, sh1z);
                 }
             } else {
-                h1x = divide<T, V>(b1x, a.mu0); h1z = divide<T, V>(b1z, a.mu0);
+                divide2<T, V>(b1x, b1z, a.dm, h1x, h1z);
             }
             if (!valid) { h1x = zero_pack<T, V>(); h1z = h1x; }
         }
@@ -270,7 +277,7 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
             T hz_l = lane_below(h1z.v[V - 1]);
             if (!INNER && lane == 0) hz_l = (T)0;
             if (k >= kb + 1 && (INNER || km < nz1)) {
-                asm volatile("" : "+s"(ap));
+                if constexpr (LZ) asm volatile("" : "+s"(ap));
                 const size_t q = (size_t)km * px + c0;
                 const bool st = own_lane && km >= kb && km < ke;
                 P d2 = d1_km;
@@ -296,7 +303,7 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
                         for (int e = 0; e < V; ++e) lorentz<T>(d2.v[e] / a.eps0, c1.v[e], c2.v[e], c3.v[e], e1_km.v[e], f2.v[e], s1e_km.v[e], s2.v[e], e2.v[e], s2e.v[e]);
                         if (st) { stg<T, V>(ap->FY[0] + q, lo, e2); stg<T, V>(ap->SY[0] + q, lo, s2e); }
                     } else {
-                        e2 = divide<T, V>(d2, a.eps0);
+                        e2 = divide<T, V>(d2, a.de);
                     }
                     if (!valid) e2 = zero_pack<T, V>();
                     if constexpr (ACC) {
@@ -314,7 +321,7 @@ __global__ void __launch_bounds__(kLanes * kPairTiles2D) k2_pair(const K2P<T> a)
         // ---------------------------------------------------------------- D: row k-2, second step: B2, H2
         const T e2_r = lane_above(e2_km2.v[0]);
         if (km2 >= kb && km2 < ke && (INNER || km2 < Nz)) {
-            asm volatile("" : "+s"(ap));
+            if constexpr (LZ) asm volatile("" : "+s"(ap));
             const size_t q = (size_t)km2 * px + c0;
             int lm;
             const int zm = INNER ? (lm = 0, (int)Z_MID) : zone_h(km2, Nz, a.np[1][0], a.np[1][1], false, lm);

@@ -208,6 +208,59 @@ __device__ __forceinline__ Pack<T, V> divide(const Pack<T, V>& n, T d) {
     return r;
 }
 
+// ---- division by a constant ------------------------------------------------------------------
+// x / c for a wave-uniform c is, for most x, q0 = x*r, q = fma(fma(-q0, c, x), r, q0) with r = 1/c rounded: three
+// instructions instead of the eleven of the hardware's IEEE sequence.  "Most" is made exact by the host: when an engine
+// is created it runs EVERY fp32 bit pattern x of the class below through both and only sets `fast` if all quotients
+// agree bit for bit (fdtd_const_division_proven).  The class: |x| in [lo, hi], or x = +0.  A wave takes the short
+// sequence when all its numerators are in the class, the IEEE division otherwise (NaN, infinities, denormals, -0,
+// huge and tiny values), so the result is the IEEE quotient always.  fp64 always divides.
+template <typename T>
+struct ConstDiv { T c, r, lo, hi; int fast; };
+
+__device__ __forceinline__ bool const_div_in_class(float x, const ConstDiv<float>& d) {
+    const float m = __builtin_fabsf(x);
+    return m <= d.hi && (m >= d.lo || __builtin_amdgcn_classf(x, 0x040));       // 0x040: +0
+}
+__device__ __forceinline__ float const_div_short(float x, const ConstDiv<float>& d) {
+    const float q0 = x * d.r;
+    return __builtin_fmaf(__builtin_fmaf(-q0, d.c, x), d.r, q0);
+}
+template <typename T, int V>
+__device__ __forceinline__ Pack<T, V> divide(const Pack<T, V>& n, const ConstDiv<T>& d) {
+    if constexpr (sizeof(T) == 4) {
+        if (d.fast) {
+            bool ok = true;
+#pragma unroll
+            for (int e = 0; e < V; ++e) ok = ok && const_div_in_class(n.v[e], d);
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
+                Pack<T, V> r;
+#pragma unroll
+                for (int e = 0; e < V; ++e) r.v[e] = const_div_short(n.v[e], d);
+                return r;
+            }
+        }
+    }
+    return divide<T, V>(n, d.c);
+}
+// two packs with one decision
+template <typename T, int V>
+__device__ __forceinline__ void divide2(const Pack<T, V>& n0, const Pack<T, V>& n1, const ConstDiv<T>& d, Pack<T, V>& q0, Pack<T, V>& q1) {
+    if constexpr (sizeof(T) == 4) {
+        if (d.fast) {
+            bool ok = true;
+#pragma unroll
+            for (int e = 0; e < V; ++e) ok = ok && const_div_in_class(n0.v[e], d) && const_div_in_class(n1.v[e], d);
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) { q0.v[e] = const_div_short(n0.v[e], d); q1.v[e] = const_div_short(n1.v[e], d); }
+                return;
+            }
+        }
+    }
+    q0 = divide<T, V>(n0, d.c); q1 = divide<T, V>(n1, d.c);
+}
+
 // ---- loop-invariant per-lane state of the 3-D kernels ---------------------------------------
 template <typename T, int V>
 struct Lane3 {

@@ -41,6 +41,12 @@ const char* fdtd_last_error(void);
 const char* fdtd_engine_version(void);
 /* Number of HIP devices this process can use (0 if there is none). */
 int fdtd_device_count(void);
+/* fp32 division by a constant (eps0, mu0 in the 2-D two-step kernel): 1 if the three-instruction form x*r corrected by
+ * two fused multiply-adds has been proven, by running every fp32 numerator of its class (|x| within 2^-80..2^80 scaled
+ * by c, or +0) through both on the current device, to give the IEEE quotient bit for bit -- the kernels then use it for
+ * waves whose numerators are all in the class and the IEEE division otherwise; 0 if not (the kernels always divide);
+ * -1 on error.  The environment variable FDTD_CONST_DIV=0 turns the short form off. */
+int fdtd_const_division_proven(double c);
 
 /* ------------------------------------------------------------------ 3-D -- */
 

@@ -208,6 +208,40 @@ def test_window_inside_two_step_launches_2d(prec, window):
     compare_2d(eng, tw.get, meta["Nx"], meta["Nz"], meta["npml"], mask, f"fp{prec} after {n} observed steps")
 
 
+def test_short_division_by_a_constant_is_proven_and_the_proof_can_fail(monkeypatch):
+    """The two-step kernel divides by eps0 and mu0 with x*r corrected by two fused multiply-adds where the library has
+    proven, over every fp32 numerator of the class it uses it for, that this is the IEEE quotient.  The proof holds for the
+    constants of the reference and for a handful of others; run over ALL magnitudes instead (denormals, values whose
+    quotient overflows) it finds disagreements, i.e. it is a test that can fail; and a run with the short form switched off
+    leaves the same bits."""
+    import ctypes
+    L = fdtd_amd.lib()
+    L.fdtd_const_division_proven.argtypes = [ctypes.c_double]
+    L.fdtd_const_division_proven.restype = ctypes.c_int
+    L.fdtd_const_division_mismatches.argtypes = [ctypes.c_double] * 3
+    L.fdtd_const_division_mismatches.restype = ctypes.c_longlong
+    K = po.consts()
+    for c in (K["eps0"], K["mu0"], 1.0, 3.0, 0.1, 7.77e5, 1.2345e-3):
+        assert L.fdtd_const_division_proven(c) == 1, c
+        lo, hi = 2.0 ** -80 * max(1.0, c), 2.0 ** 80 * min(1.0, c)
+        assert L.fdtd_const_division_mismatches(c, lo, hi) == 0
+    fmax = float(np.finfo(np.float32).max)
+    assert L.fdtd_const_division_mismatches(K["eps0"], 0.0, fmax) > 0          # quotients overflow, tiny remainders are inexact
+    assert L.fdtd_const_division_mismatches(3.0, 0.0, 2.0 ** 80) > 0           # denormal numerators
+    meta, ins, _, _ = util.load_fixture("g4_2d_slab")
+    got = []
+    for switch in ("1", "0"):
+        monkeypatch.setenv("FDTD_CONST_DIV", switch)
+        monkeypatch.setenv("FDTD2D_PAIR", "1")
+        eng = fdtd_amd.Engine2D(meta["Nx"], meta["Nz"], meta["npml"], meta["dx"], meta["dz"], meta["dt"], meta["mu0"], meta["eps0"],
+                                meta["i_Jy"], meta["k_Jy"], meta["steps"], precision=32, mode=MODE2D_FUSED)
+        util.feed(eng, ins)
+        eng.step(0, 40)
+        got.append([eng.get(i) for i in (po.D2_DY, po.D2_BX, po.D2_BZ)])
+    for a_, b_ in zip(*got):
+        assert np.array_equal(a_.view(np.uint64), b_.view(np.uint64))
+
+
 def test_observed_steps_two_kernel_mode_2d():
     """Engines that keep every array of the reference (two kernels per step) take the same call: step, then the observe
     kernel, and the completed window is kept the same way."""
